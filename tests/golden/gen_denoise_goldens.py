@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Generate golden vectors for the denoiser by importing the REFERENCE model.
+
+Runs only in the build container, where /root/reference exists (it does not travel to the
+GPU box).  Imports /root/reference/training/recurrent_autoencoder_model.py unmodified, loads
+this repo's deterministic synthetic weights into it (load_state_dict), runs it on this repo's
+deterministic synthetic G-buffers and stores the OUTPUTS (data, not source) as .npz fixtures:
+
+  * bn=batch  : model left in train() mode -- the semantics of the reference's shipped
+                TorchScript (convert_to_torchscript.py:26-30 never calls .eval())
+  * bn=running: model.eval() -- what training/test.py:35 uses
+  * hidden reset: model(x, 0) each frame (forward j==0 re-inits hidden, model.py:121-128)
+  * hidden carry: model(x_0, 0), model(x_1, 1), ... (test.py:46-48)
+
+Inputs and weights are NOT stored: tests regenerate them bit-identically from
+ai_path_tracer_denoiser_amd/synth.py.  Stored per case: every output frame in full, plus for
+the 6 hidden states after the last frame per-channel mean/mean-square (fp64) and 512 strided
+samples.
+
+Usage: python tests/golden/gen_denoise_goldens.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/training")
+
+import recurrent_autoencoder_model as M  # noqa: E402  (the reference, imported as-is)
+
+from ai_path_tracer_denoiser_amd import arch, synth  # noqa: E402
+
+CASES = [
+    # name,            H,  W,  wseed, iseed, bn,        frames (carry if >1)
+    ("b_reset_64",     64, 64,  565,  0, "batch",   1),
+    ("r_reset_64",     64, 64,  565,  0, "running", 1),
+    ("b_carry_64",     64, 64,  565,  0, "batch",   3),
+    ("r_carry_64",     64, 64,  565,  0, "running", 3),
+    ("b_carry_96x160", 96, 160, 566,  1, "batch",   2),
+    ("r_reset_96x160", 96, 160, 566,  1, "running", 1),
+]
+
+
+def hidden_summary(h):
+    h = h.astype(np.float64)
+    c = h.shape[0]
+    flat = h.reshape(c, -1)
+    samples = h.reshape(-1)
+    idx = np.linspace(0, samples.size - 1, 512).astype(np.int64)
+    return flat.mean(axis=1), (flat * flat).mean(axis=1), samples[idx].astype(np.float32), idx
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    for name, H, W, wseed, iseed, bn, frames in CASES:
+        params = synth.make_params(wseed)
+        model = M.AutoEncoder(10)
+        sd = {k: torch.from_numpy(np.array(v)) for k, v in arch.state_dict_from_params(params).items()}
+        missing = model.load_state_dict(sd, strict=False)
+        # only num_batches_tracked buffers may be missing
+        assert all(k.endswith("num_batches_tracked") for k in missing.missing_keys), missing
+        assert not missing.unexpected_keys
+        if bn == "running":
+            model.eval()
+        else:
+            model.train()
+        outs = []
+        with torch.no_grad():
+            for j in range(frames):
+                x = torch.from_numpy(synth.make_gbuffer(H, W, iseed, j))[None]
+                y = model(x, j)          # j==0 resets hidden; j>0 carries (model.py:120-128)
+                outs.append(y[0].numpy().copy())
+        blocks = [model.encoder1[0], model.encoder2[0], model.encoder3[0], model.encoder4[0],
+                  model.encoder5[0], model.bottleneck]
+        store = {"out": np.stack(outs).astype(np.float32),
+                 "meta": np.array([H, W, wseed, iseed, frames, 1 if bn == "batch" else 0], np.int64)}
+        for lvl, b in enumerate(blocks):
+            m1, m2, smp, idx = hidden_summary(b.hidden[0].numpy())
+            store[f"h{lvl}_mean"] = m1
+            store[f"h{lvl}_msq"] = m2
+            store[f"h{lvl}_samples"] = smp
+            store[f"h{lvl}_idx"] = idx
+        path = os.path.join(HERE, f"denoise_{name}.npz")
+        np.savez_compressed(path, **store)
+        print(name, "out range", float(store["out"].min()), float(store["out"].max()),
+              os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

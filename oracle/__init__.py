@@ -93,3 +93,201 @@ class DenoiseOracle:
         s = np.empty(28, np.float64)
         lib().orc_dn_conv_checksums(self._h, s.ctypes.data)
         return s
+
+
+# --------------------------------------------------------------------------- trace oracle
+class Geom(C.Structure):          # sceneStructs.h:20 (248 B)
+    _fields_ = [("type", C.c_int), ("materialid", C.c_int),
+                ("translation", C.c_float * 3), ("rotation", C.c_float * 3), ("scale", C.c_float * 3),
+                ("transform", C.c_float * 16), ("inverseTransform", C.c_float * 16),
+                ("invTranspose", C.c_float * 16), ("vel", C.c_float * 3)]
+
+
+class Face(C.Structure):          # sceneStructs.h:40 (76 B)
+    _fields_ = [("v", (C.c_float * 3) * 3), ("n", (C.c_float * 3) * 3), ("materialid", C.c_int)]
+
+
+class Material(C.Structure):      # sceneStructs.h:46 (44 B)
+    _fields_ = [("color", C.c_float * 3), ("spec_exponent", C.c_float), ("spec_color", C.c_float * 3),
+                ("hasReflective", C.c_float), ("hasRefractive", C.c_float),
+                ("indexOfRefraction", C.c_float), ("emittance", C.c_float)]
+
+
+class Camera(C.Structure):        # sceneStructs.h:58 (84 B)
+    _fields_ = [("res", C.c_int * 2), ("position", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("view", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("fov", C.c_float * 2), ("pixelLength", C.c_float * 2)]
+
+
+class AABB(C.Structure):          # sceneStructs.h:84 (24 B)
+    _fields_ = [("lb", C.c_float * 3), ("ub", C.c_float * 3)]
+
+
+assert (C.sizeof(Geom), C.sizeof(Face), C.sizeof(Material), C.sizeof(Camera), C.sizeof(AABB)) == (248, 76, 44, 84, 24)
+
+SPHERE, CUBE = 0, 1
+
+
+def _trace_lib():
+    L = lib()
+    if not getattr(L, "_trace_ready", False):
+        L.orc_utilhash.restype = C.c_uint32
+        L.orc_utilhash.argtypes = [C.c_uint32]
+        L.orc_seed.restype = C.c_uint32
+        L.orc_seed.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_lcg_next.restype = C.c_uint32
+        L.orc_lcg_next.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_u01.restype = C.c_float
+        L.orc_u01.argtypes = [C.POINTER(C.c_uint32), C.c_float, C.c_float]
+        L.orc_det_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_hemisphere.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p]
+        for f in (L.orc_box_test, L.orc_sphere_test):
+            f.restype = C.c_float
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_triangle_test.restype = C.c_float
+        L.orc_triangle_test.argtypes = [C.c_void_p] * 5
+        L.orc_ray_aabb.restype = C.c_int
+        L.orc_ray_aabb.argtypes = [C.c_void_p] * 3
+        L.orc_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_intersect_scene.restype = C.c_float
+        L.orc_intersect_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]
+        L.orc_pathtrace.restype = C.c_int
+        L.orc_pathtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_build_geom.argtypes = [C.c_void_p]
+        L.orc_camera_setup.argtypes = [C.c_void_p, C.c_float]
+        L.orc_camera_orbit_params.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
+        L.orc_camera_orbit.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+        L._trace_ready = True
+    return L
+
+
+class OracleScene:
+    """Scene arrays for the trace oracle.  ``parse`` is a small test-side reader of the reference's
+    scene grammar (scene.cpp:21-40, 44-100, 102-159, 161-196) -- independent of the product's C++ parser."""
+
+    def __init__(self):
+        self.geoms, self.materials, self.faces = [], [], []
+        self.camera = Camera()
+        self.mesh_box = AABB()
+        self.fovy = 45.0
+        self.depth = 8
+        self.iterations = 1
+
+    @staticmethod
+    def parse(path, res=None, depth=None):
+        L = _trace_lib()
+        s = OracleScene()
+        with open(path) as f:
+            lines = [ln.strip() for ln in f.read().replace("\r\n", "\n").split("\n")]
+        i = 0
+
+        def nxt():
+            nonlocal i
+            ln = lines[i] if i < len(lines) else ""
+            i += 1
+            return ln
+
+        while i < len(lines):
+            ln = nxt()
+            tok = ln.split()
+            if not tok:
+                continue
+            if tok[0] == "MATERIAL":
+                m = Material()
+                for _ in range(7):                      # exactly 7 lines (scene.cpp:171)
+                    t = nxt().split()
+                    if t[0] == "RGB":
+                        m.color[:] = [float(v) for v in t[1:4]]
+                    elif t[0] == "SPECEX":
+                        m.spec_exponent = float(t[1])
+                    elif t[0] == "SPECRGB":
+                        m.spec_color[:] = [float(v) for v in t[1:4]]
+                    elif t[0] == "REFL":
+                        m.hasReflective = float(t[1])
+                    elif t[0] == "REFR":
+                        m.hasRefractive = float(t[1])
+                    elif t[0] == "REFRIOR":
+                        m.indexOfRefraction = float(t[1])
+                    elif t[0] == "EMITTANCE":
+                        m.emittance = float(t[1])
+                s.materials.append(m)
+            elif tok[0] == "OBJECT":
+                g = Geom()
+                kind = nxt()
+                g.type = SPHERE if kind == "sphere" else CUBE
+                g.materialid = int(nxt().split()[1])
+                ln2 = nxt()
+                while ln2:
+                    t = ln2.split()
+                    vals = [float(v) for v in t[1:4]]
+                    if t[0] == "TRANS":
+                        g.translation[:] = vals
+                    elif t[0] == "ROTAT":
+                        g.rotation[:] = vals
+                    elif t[0] == "SCALE":
+                        g.scale[:] = vals
+                    elif t[0] == "VEL":
+                        g.vel[:] = vals
+                    ln2 = nxt()
+                L.orc_build_geom(C.byref(g))
+                s.geoms.append(g)
+            elif tok[0] == "CAMERA":
+                cam = s.camera
+                for _ in range(5):                      # exactly 5 lines (scene.cpp:109)
+                    t = nxt().split()
+                    if t[0] == "RES":
+                        cam.res[:] = [int(t[1]), int(t[2])]
+                    elif t[0] == "FOVY":
+                        s.fovy = float(t[1])
+                    elif t[0] == "ITERATIONS":
+                        s.iterations = int(t[1])
+                    elif t[0] == "DEPTH":
+                        s.depth = int(t[1])
+                ln2 = nxt()
+                while ln2:
+                    t = ln2.split()
+                    vals = [float(v) for v in t[1:4]]
+                    if t[0] == "EYE":
+                        cam.position[:] = vals
+                    elif t[0] == "LOOKAT":
+                        cam.lookAt[:] = vals
+                    elif t[0] == "UP":
+                        cam.up[:] = vals
+                    ln2 = nxt()
+        if res is not None:
+            s.camera.res[:] = list(res)
+        if depth is not None:
+            s.depth = depth
+        L.orc_camera_setup(C.byref(s.camera), C.c_float(s.fovy))
+        z, p, t = C.c_float(), C.c_float(), C.c_float()
+        L.orc_camera_orbit_params(C.byref(s.camera), C.byref(z), C.byref(p), C.byref(t))
+        s.zoom, s.phi, s.theta = z.value, p.value, t.value
+        s.set_orbit(s.zoom, s.phi, s.theta)
+        return s
+
+    def set_orbit(self, zoom, phi, theta):
+        """runCuda() camera rebuild (main.cpp:122-140)."""
+        _trace_lib().orc_camera_orbit(C.byref(self.camera), C.c_float(zoom), C.c_float(phi), C.c_float(theta))
+
+    def arrays(self):
+        ga = (Geom * max(1, len(self.geoms)))(*self.geoms)
+        ma = (Material * max(1, len(self.materials)))(*self.materials)
+        fa = (Face * max(1, len(self.faces)))(*self.faces)
+        return ga, ma, fa
+
+    def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True):
+        """One 1-spp frame (pathtrace.cu:422-528).  Returns (gbuf[10,Hp,W], n_live[depth+1], mat0[H*W])."""
+        L = _trace_lib()
+        W, H = self.camera.res[0], self.camera.res[1]
+        Hp = pad_rows_to or H
+        depth = depth or self.depth
+        gbuf = np.zeros((10, Hp, W), np.float32)
+        n_live = np.full(depth + 1, -1, np.int32)
+        mat0 = np.full(W * H, -2, np.int32)
+        ga, ma, fa = self.arrays()
+        nb = L.orc_pathtrace(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
+                             len(self.faces), C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
+                             n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None)
+        return gbuf, n_live[:nb + 1], mat0

@@ -1,0 +1,193 @@
+"""Pin the CPU trace oracle.
+
+The reference has no tests for this path and its headers cannot be built here without a stand-in
+<cuda_runtime.h>, so the pins are the known answers SURVEY.md (Appendix B, F8) recorded from the reference
+headers run in the survey container, plus the C++ standard's minstd_rand check value, plus structural
+properties of pathtrace() that follow from the reference source (cited inline)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import OracleScene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORNELL = os.path.join(ROOT, "scenes", "cornell.txt")
+
+
+@pytest.fixture(scope="module")
+def L():
+    return oracle._trace_lib()
+
+
+def test_minstd_10000th(L):
+    # thrust::minstd_rand == std::minstd_rand: 10000th draw from the default seed is 399268537
+    x = C.c_uint32(1)
+    for _ in range(10000):
+        v = L.orc_lcg_next(C.byref(x))
+    assert v == 399268537
+
+
+def test_seed_and_u01_known_answers(L):
+    # utilhash((1<<31)|(8<<22)|1) ^ utilhash(12345) = 939298829 -> draws 0.498972625, 0.907480478
+    h = (L.orc_utilhash((1 << 31) | (8 << 22) | 1) ^ L.orc_utilhash(12345)) & 0xFFFFFFFF
+    assert h == 939298829
+    assert L.orc_seed(1, 12345, 8) == h % 2147483647
+    s = C.c_uint32(L.orc_seed(1, 12345, 8))
+    a = L.orc_u01(C.byref(s), 0.0, 1.0)
+    b = L.orc_u01(C.byref(s), 0.0, 1.0)
+    assert np.float32(a) == np.float32(0.498972625) and np.float32(b) == np.float32(0.907480478)
+    # calculateRandomDirectionInHemisphere((0,1,0)) with the engine's next draws
+    n = np.array([0, 1, 0], np.float32)
+    out = np.zeros(3, np.float32)
+    L.orc_hemisphere(n.ctypes.data, C.byref(s), out.ctypes.data)
+    np.testing.assert_allclose(out, [-0.0120381089, 0.99536413, 0.0954217315], rtol=0, atol=2e-7)
+
+
+def test_u01_top_states_round_to_one(L):
+    # SURVEY 7 "minstd on GPU": float(x-1)/2^31 rounds to exactly 1.0f for the top states -- keep it.
+    s = C.c_uint32(0)
+    # find x with lcg(x) = m-1: x = (m-1) * inv(48271) mod m; easier: brute-force check of the mapping itself
+    r = np.float32(np.float32(2147483646 - 1) / np.float32(2147483648.0))
+    assert r == np.float32(1.0)
+
+
+def test_det_sincos_accuracy(L):
+    xs = np.linspace(0, 2 * np.pi, 20001).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    es = ec = 0.0
+    for x in xs[::7]:
+        L.orc_det_sincosf(C.c_float(x), C.byref(s), C.byref(c))
+        es = max(es, abs(s.value - np.sin(np.float64(x))))
+        ec = max(ec, abs(c.value - np.cos(np.float64(x))))
+    assert es < 2.5e-7 and ec < 2.5e-7
+
+
+def test_triangle_f8_quirk(L):
+    # ray (0.6,0.1,1) -> -z on the unit triangle returns p=(0.1,0.3,0), t=1, correct normal weights
+    f = oracle.Face()
+    f.v[0][:] = [0, 0, 0]; f.v[1][:] = [1, 0, 0]; f.v[2][:] = [0, 1, 0]
+    for k in range(3):
+        f.n[k][:] = [0, 0, 1]
+    ro = np.array([0.6, 0.1, 1.0], np.float32)
+    rd = np.array([0, 0, -1], np.float32)
+    P = np.zeros(3, np.float32); N = np.zeros(3, np.float32)
+    t = L.orc_triangle_test(C.byref(f), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data)
+    assert t == pytest.approx(1.0)
+    np.testing.assert_allclose(P, [0.1, 0.3, 0.0], atol=1e-6)
+    np.testing.assert_allclose(N, [0, 0, 1], atol=1e-6)
+    # back face is culled: glm::intersectRayTriangle rejects a < epsilon (intersect.inl:51-53)
+    ro2 = np.array([0.6, 0.1, -1.0], np.float32); rd2 = np.array([0, 0, 1], np.float32)
+    assert L.orc_triangle_test(C.byref(f), ro2.ctypes.data, rd2.ctypes.data, P.ctypes.data, N.ctypes.data) == -1
+
+
+def test_box_and_sphere_tests(L):
+    g = oracle.Geom(); g.type = oracle.CUBE
+    g.translation[:] = [0, 0, 0]; g.rotation[:] = [0, 0, 0]; g.scale[:] = [2, 2, 2]
+    L.orc_build_geom(C.byref(g))
+    assert np.allclose(np.array(g.transform).reshape(4, 4), np.diag([2, 2, 2, 1]))
+    assert np.allclose(np.array(g.inverseTransform).reshape(4, 4), np.diag([.5, .5, .5, 1]))
+    ro = np.array([0, 0, 5], np.float32); rd = np.array([0, 0, -1], np.float32)
+    P = np.zeros(3, np.float32); N = np.zeros(3, np.float32); o = C.c_int(0)
+    t = L.orc_box_test(C.byref(g), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data, C.byref(o))
+    # hit the +z face at z=1 (minus getPointOnRay's 1e-4 in object space -> 2e-4 in world)
+    assert t == pytest.approx(4.0, abs=1e-3) and o.value == 1
+    np.testing.assert_allclose(N, [0, 0, 1], atol=1e-6)
+    # from inside: exits through -z, outside flag false (intersections.h:84-88)
+    ro[:] = [0, 0, 0]
+    t = L.orc_box_test(C.byref(g), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data, C.byref(o))
+    assert t == pytest.approx(1.0, abs=1e-3) and o.value == 0
+    s = oracle.Geom(); s.type = oracle.SPHERE
+    s.translation[:] = [0, 0, 0]; s.rotation[:] = [0, 0, 0]; s.scale[:] = [2, 2, 2]   # radius 1
+    L.orc_build_geom(C.byref(s))
+    ro[:] = [0, 0, 5]
+    t = L.orc_sphere_test(C.byref(s), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data, C.byref(o))
+    assert t == pytest.approx(4.0, abs=1e-3) and o.value == 1
+    np.testing.assert_allclose(N, [0, 0, 1], atol=1e-5)
+    ro[:] = [0, 0, 0]     # inside: normal flipped (intersections.h:143-145)
+    t = L.orc_sphere_test(C.byref(s), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data, C.byref(o))
+    assert t == pytest.approx(1.0, abs=1e-3) and o.value == 0
+    np.testing.assert_allclose(N, [0, 0, 1], atol=1e-5)
+    ro[:] = [3, 0, 5]     # miss
+    assert L.orc_sphere_test(C.byref(s), ro.ctypes.data, rd.ctypes.data, P.ctypes.data, N.ctypes.data, C.byref(o)) == -1
+
+
+def test_rotated_geom_matrices(L):
+    g = oracle.Geom(); g.type = oracle.CUBE
+    g.translation[:] = [1, 2, 3]; g.rotation[:] = [10, 20, 30]; g.scale[:] = [.5, 2, 3]
+    L.orc_build_geom(C.byref(g))
+    M = np.array(g.transform, np.float64).reshape(4, 4).T      # column-major -> row/col
+    Mi = np.array(g.inverseTransform, np.float64).reshape(4, 4).T
+    Mit = np.array(g.invTranspose, np.float64).reshape(4, 4).T
+    np.testing.assert_allclose(M @ Mi, np.eye(4), atol=1e-5)
+    np.testing.assert_allclose(Mit, np.linalg.inv(M).T, atol=1e-5)
+    rx, ry, rz = np.radians([10, 20, 30])
+    Rx = np.array([[1, 0, 0], [0, np.cos(rx), -np.sin(rx)], [0, np.sin(rx), np.cos(rx)]])
+    Ry = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+    Rz = np.array([[np.cos(rz), -np.sin(rz), 0], [np.sin(rz), np.cos(rz), 0], [0, 0, 1]])
+    np.testing.assert_allclose(M[:3, :3], Rx @ Ry @ Rz @ np.diag([.5, 2, 3]), atol=1e-6)
+    np.testing.assert_allclose(M[:3, 3], [1, 2, 3])
+
+
+def test_cornell_camera():
+    sc = OracleScene.parse(CORNELL, res=(256, 256), depth=4)
+    cam = sc.camera
+    # FOVY 45 used as the half-angle: yscaled = tan(45 deg) = 1 (scene.cpp:143) -> pixelLength = 2/256
+    assert list(cam.pixelLength) == pytest.approx([2 / 256, 2 / 256])
+    assert sc.zoom == pytest.approx(10.5) and sc.phi == pytest.approx(0.0) and sc.theta == pytest.approx(np.pi / 2)
+    np.testing.assert_allclose(list(cam.position), [0, 5, 10.5], atol=1e-5)
+    np.testing.assert_allclose(list(cam.view), [0, 0, -1], atol=1e-6)
+    np.testing.assert_allclose(list(cam.right), [1, 0, 0], atol=1e-6)   # cross(view, (0,1,0)), un-normalised
+
+
+@pytest.fixture(scope="module")
+def cornell_frame():
+    sc = OracleScene.parse(CORNELL, res=(128, 96), depth=4)
+    return sc, sc.pathtrace()
+
+
+def test_cornell_frame_structure(cornell_frame):
+    sc, (g, n_live, mat0) = cornell_frame
+    W, H = 128, 96
+    assert g.shape == (10, H, W)
+    assert n_live[0] == W * H and all(n_live[i] >= n_live[i + 1] for i in range(len(n_live) - 1))
+    assert n_live[-1] == 0                      # depth exhausted: every survivor has remainingBounces 0
+    hit = (mat0 >= 0).reshape(H, W)[:, ::-1]    # G-buffer is h-flipped relative to pixelIndex (pathtrace.cu:297-299)
+    nlen = np.sqrt((g[3:6] ** 2).sum(0))
+    assert np.allclose(nlen[hit], 1.0, atol=1e-5) and np.all(nlen[~hit] == 0)
+    assert np.all(g[6][hit] > 0) and np.all(g[6][~hit] == 0)
+    # albedo plane = material colour (x emittance on the light) for first hits (pathtrace.cu:379-387)
+    m = mat0.reshape(H, W)[:, ::-1]
+    for mid, mat in enumerate(sc.materials):
+        sel = m == mid
+        if not sel.any():
+            continue
+        if mat.emittance > 0:
+            expect = np.array(mat.color[:]) * mat.emittance
+        elif mat.hasRefractive or mat.hasReflective:
+            continue                            # specular vs diffuse colour depends on the random branch
+        else:
+            expect = np.array(mat.color[:])
+        for c in range(3):
+            assert np.allclose(g[7 + c][sel], expect[c], atol=1e-6)
+    assert np.all(g[0:3] >= 0) and g[0:3].max() <= 5.0 + 1e-5
+    assert 0.05 < g[0:3].mean() < 1.0
+
+
+def test_cornell_frame_deterministic_and_seeded_by_iter(cornell_frame):
+    sc, (g, n_live, mat0) = cornell_frame
+    g2, n2, m2 = sc.pathtrace()
+    assert np.array_equal(g, g2) and np.array_equal(n_live, n2)     # F6: constant seed => identical frames
+    g3, _, _ = sc.pathtrace(iter=1, depth=2)
+    assert not np.array_equal(g[0:3], g3[0:3])                       # depth changes the radiance planes ...
+    assert np.array_equal(g[3:10], g3[3:10])                         # ... but not the first-hit planes
+
+
+def test_padded_rows_stay_zero():
+    sc = OracleScene.parse(CORNELL, res=(64, 40), depth=3)
+    g, n_live, _ = sc.pathtrace(pad_rows_to=64)
+    assert g.shape == (10, 64, 64) and np.all(g[:, 40:, :] == 0)
+    g0, _, _ = sc.pathtrace()
+    assert np.array_equal(g[:, :40, :], g0)

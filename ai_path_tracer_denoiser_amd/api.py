@@ -1,0 +1,237 @@
+"""ctypes binding of libaiptd.so (include/aiptd.h) and a thin host-side mirror of the
+reference's interface for the hot path.
+
+Reference interface mirrored (Inference/src):
+    pathtraceInit(Scene*) / pathtrace(pbo, frame, iter) / pathtraceFree()   pathtrace.h:6-8
+    torch::jit::load + module.forward                                        main.cpp:104-111
+    runCuda() per-frame body                                                 main.cpp:143-163
+
+torch is used only as plumbing (device buffers, stream handles); every computation happens in
+the HIP library.  There is no fallback: if libaiptd.so is missing or no GPU is visible, the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaiptd.so")
+
+# flags (include/aiptd.h)
+TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0 = 1, 2, 4
+TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
+DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
+DN_IMPL_MFMA, DN_IMPL_VALU = 0, 1
+GEOM_SPHERE, GEOM_CUBE = 0, 1
+
+
+class Geom(C.Structure):
+    _fields_ = [("type", C.c_int), ("materialid", C.c_int),
+                ("translation", C.c_float * 3), ("rotation", C.c_float * 3), ("scale", C.c_float * 3),
+                ("transform", C.c_float * 16), ("inverseTransform", C.c_float * 16),
+                ("invTranspose", C.c_float * 16), ("vel", C.c_float * 3)]
+
+
+class Face(C.Structure):
+    _fields_ = [("v", (C.c_float * 3) * 3), ("n", (C.c_float * 3) * 3), ("materialid", C.c_int)]
+
+
+class Material(C.Structure):
+    _fields_ = [("color", C.c_float * 3), ("specular_exponent", C.c_float), ("specular_color", C.c_float * 3),
+                ("hasReflective", C.c_float), ("hasRefractive", C.c_float),
+                ("indexOfRefraction", C.c_float), ("emittance", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("resolution", C.c_int * 2), ("position", C.c_float * 3), ("lookAt", C.c_float * 3),
+                ("view", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
+                ("fov", C.c_float * 2), ("pixelLength", C.c_float * 2)]
+
+
+class AABB(C.Structure):
+    _fields_ = [("lb", C.c_float * 3), ("ub", C.c_float * 3)]
+
+
+assert (C.sizeof(Geom), C.sizeof(Face), C.sizeof(Material), C.sizeof(Camera), C.sizeof(AABB)) == (248, 76, 44, 84, 24)
+
+# every symbol include/aiptd.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+ABI = [
+    ("aipt_create", C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    ("aipt_destroy", None, [_P]),
+    ("aipt_last_error", C.c_char_p, [_P]),
+    ("aipt_abi_version", C.c_int, []),
+    ("aipt_sync", C.c_int, [_P]),
+    ("aipt_malloc", C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    ("aipt_free", C.c_int, [_P, _P]),
+    ("aipt_upload", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("aipt_download", C.c_int, [_P, _P, _P, C.c_size_t]),
+    ("aipt_memset", C.c_int, [_P, _P, C.c_int, C.c_size_t]),
+    ("aipt_timer_start", C.c_int, [_P]),
+    ("aipt_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
+    ("aipt_scene_upload", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
+    ("aipt_scene_free", C.c_int, [_P]),
+    ("aipt_trace_configure", C.c_int, [_P, C.c_int, C.c_int]),
+    ("aipt_trace", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, _P, C.c_int, C.c_int]),
+    ("aipt_trace_live_counts", C.c_int, [_P, _P, C.c_int]),
+    ("aipt_trace_first_hit_materials", C.c_int, [_P, _P, C.c_int]),
+    ("aipt_denoise_load_weights", C.c_int, [_P, _P, C.c_size_t]),
+    ("aipt_denoise_configure", C.c_int, [_P, C.c_int, C.c_int]),
+    ("aipt_denoise_set_impl", C.c_int, [_P, C.c_int]),
+    ("aipt_denoise", C.c_int, [_P, _P, _P, C.c_uint32]),
+    ("aipt_denoise_reset_hidden", C.c_int, [_P]),
+    ("aipt_denoise_get_hidden", C.c_int, [_P, C.c_int, _P]),
+    ("aipt_denoise_set_hidden", C.c_int, [_P, C.c_int, _P]),
+    ("aipt_frame_configure", C.c_int, [_P, C.c_int, C.c_int]),
+    ("aipt_frame", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
+    ("aipt_gbuffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("aipt_frame_set_timing", C.c_int, [_P, C.c_int]),
+    ("aipt_frame_last_times", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+]
+
+_LIB = None
+
+
+class AiptError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libaiptd.so; raises if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise AiptError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(hipcc --offload-arch=gfx950); this package has no CPU or PyTorch fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in ABI:
+            fn = getattr(L, name)          # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+class Context:
+    """One context per GPU (aipt_create).  stream: a raw hipStream_t handle (int) or None."""
+
+    def __init__(self, device: int = 0, stream=None):
+        L = lib()
+        h = _P()
+        rc = L.aipt_create(device, _P(stream) if stream else None, C.byref(h))
+        if rc:
+            raise AiptError(f"aipt_create failed ({rc}): {L.aipt_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().aipt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise AiptError(f"libaiptd error {rc}: {lib().aipt_last_error(self._h).decode()}")
+
+    def sync(self):
+        self._ck(lib().aipt_sync(self._h))
+
+    def timer_start(self):
+        self._ck(lib().aipt_timer_start(self._h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._ck(lib().aipt_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------ trace (pathtrace.h:6-8)
+    def pathtrace_init(self, geoms, materials, faces=(), mesh_box=None, width=None, height=None):
+        """pathtraceInit(Scene*): upload the scene; allocate path state for width x height."""
+        ga = (Geom * max(1, len(geoms)))(*geoms)
+        ma = (Material * max(1, len(materials)))(*materials)
+        fa = (Face * max(1, len(faces)))(*faces)
+        box = mesh_box if mesh_box is not None else AABB()
+        self._ck(lib().aipt_scene_upload(self._h, ga, len(geoms), ma, len(materials),
+                                         fa if len(faces) else None, len(faces),
+                                         C.byref(box) if len(faces) else None))
+        if width is not None:
+            self._ck(lib().aipt_trace_configure(self._h, width, height))
+
+    def pathtrace_free(self):
+        self._ck(lib().aipt_scene_free(self._h))
+
+    def pathtrace(self, cam: Camera, iter: int, depth: int, gbuf, flags: int = TRACE_DEFAULT):
+        """pathtrace(pbo, frame, iter): one 1-spp iteration into gbuf, a float32 device tensor [10, rows, stride]."""
+        assert gbuf.is_cuda and gbuf.dtype.is_floating_point and gbuf.dim() == 3 and gbuf.shape[0] == 10
+        assert gbuf.is_contiguous()
+        self._ck(lib().aipt_trace(self._h, C.byref(cam), iter, depth, flags, _P(gbuf.data_ptr()),
+                                  gbuf.shape[1], gbuf.shape[2]))
+
+    def live_counts(self, depth: int) -> np.ndarray:
+        out = np.zeros(depth + 1, np.int32)
+        self._ck(lib().aipt_trace_live_counts(self._h, out.ctypes.data, depth + 1))
+        return out
+
+    def first_hit_materials(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int32)
+        self._ck(lib().aipt_trace_first_hit_materials(self._h, out.ctypes.data, n))
+        return out
+
+    # ------------------------------------------------------------------ denoiser (main.cpp:101-118)
+    def load_weights(self, blob: bytes):
+        """torch::jit::load(MODEL_PATH) counterpart: flat blob (arch.py)."""
+        self._ck(lib().aipt_denoise_load_weights(self._h, blob, len(blob)))
+
+    def denoise_configure(self, H: int, W: int):
+        self._ck(lib().aipt_denoise_configure(self._h, H, W))
+
+    def denoise_set_impl(self, impl: int):
+        self._ck(lib().aipt_denoise_set_impl(self._h, impl))
+
+    def denoise(self, x10, out3, bn_batch: bool = True, carry: bool = False):
+        """module.forward: x10 [10,H,W] -> out3 [3,H,W], float32 contiguous device tensors."""
+        assert x10.is_cuda and out3.is_cuda and x10.is_contiguous() and out3.is_contiguous()
+        flags = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
+        self._ck(lib().aipt_denoise(self._h, _P(x10.data_ptr()), _P(out3.data_ptr()), flags))
+
+    def reset_hidden(self):
+        self._ck(lib().aipt_denoise_reset_hidden(self._h))
+
+    def get_hidden(self, level: int, dst):
+        self._ck(lib().aipt_denoise_get_hidden(self._h, level, _P(dst.data_ptr())))
+
+    def set_hidden(self, level: int, src):
+        self._ck(lib().aipt_denoise_set_hidden(self._h, level, _P(src.data_ptr())))
+
+    # ------------------------------------------------------------------ frame (runCuda, main.cpp:143-163)
+    def frame_configure(self, width: int, height: int):
+        self._ck(lib().aipt_frame_configure(self._h, width, height))
+
+    def frame(self, cam: Camera, iter: int, depth: int, out3, trace_flags: int = TRACE_DEFAULT,
+              bn_batch: bool = True, carry: bool = True):
+        flags = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
+        self._ck(lib().aipt_frame(self._h, C.byref(cam), iter, depth, trace_flags, flags, _P(out3.data_ptr())))
+
+    def gbuffer(self):
+        """(device pointer, rows, stride) of the context-owned padded G-buffer."""
+        p, r, s = _P(), C.c_int(), C.c_int()
+        self._ck(lib().aipt_gbuffer(self._h, C.byref(p), C.byref(r), C.byref(s)))
+        return p.value, r.value, s.value
+
+    def frame_set_timing(self, on: bool):
+        self._ck(lib().aipt_frame_set_timing(self._h, 1 if on else 0))
+
+    def frame_last_times(self):
+        a, b = C.c_float(), C.c_float()
+        self._ck(lib().aipt_frame_last_times(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

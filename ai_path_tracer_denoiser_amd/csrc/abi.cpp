@@ -1,0 +1,236 @@
+// abi.cpp -- context, error reporting, memory/timer helpers and the per-frame pipeline of libaiptd.so.
+// Boundary: include/aiptd.h.  aipt_frame replaces the body of runCuda() (reference Inference/src/main.cpp:143-163):
+// the G-buffer stays in HBM between the trace and the denoiser (the reference round-trips it through host memory,
+// pathtrace.cu:525 + main.cpp:104-105).
+#include "internal.h"
+
+#include <cstring>
+#include <mutex>
+
+namespace aipt {
+
+static std::mutex g_err_mu;
+static std::string g_err;
+
+void set_global_error(const char* msg) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = msg;
+}
+
+int fail(aipt_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else set_global_error(buf);
+    return code;
+}
+
+}  // namespace aipt
+
+using aipt::fail;
+
+extern "C" {
+
+int aipt_abi_version(void) { return AIPT_ABI_VERSION; }
+
+int aipt_create(int device, void* stream, aipt_ctx** out) {
+    if (!out) return fail(nullptr, AIPT_E_INVALID, "aipt_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, AIPT_E_HIP, "aipt_create: no HIP device (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device < 0 || device >= ndev) return fail(nullptr, AIPT_E_INVALID, "aipt_create: device %d of %d", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, AIPT_E_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, AIPT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (!strstr(prop.gcnArchName, "gfx950"))
+        return fail(nullptr, AIPT_E_HIP, "aipt_create: device is %s; kernels are built for gfx950 only", prop.gcnArchName);
+    aipt_ctx* ctx = new (std::nothrow) aipt_ctx();
+    if (!ctx) return fail(nullptr, AIPT_E_NOMEM, "aipt_create: out of host memory");
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return fail(nullptr, AIPT_E_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    for (auto& ev : ctx->fev) hipEventCreate(&ev);
+    *out = ctx;
+    return AIPT_OK;
+}
+
+void aipt_destroy(aipt_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    aipt::trace_destroy(ctx);
+    aipt::denoise_destroy(ctx);
+    if (ctx->d_gbuf) hipFree(ctx->d_gbuf);
+    if (ctx->d_out_pad) hipFree(ctx->d_out_pad);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    for (auto& ev : ctx->fev) if (ev) hipEventDestroy(ev);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* aipt_last_error(const aipt_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(aipt::g_err_mu);
+    static thread_local std::string copy;
+    copy = aipt::g_err;
+    return copy.c_str();
+}
+
+int aipt_sync(aipt_ctx* ctx) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_malloc(aipt_ctx* ctx, size_t bytes, void** d_out) {
+    AIPT_CHECK_CTX(ctx);
+    if (!d_out) return fail(ctx, AIPT_E_INVALID, "aipt_malloc: d_out is NULL");
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_out, bytes ? bytes : 1);
+    if (e != hipSuccess) return fail(ctx, AIPT_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return AIPT_OK;
+}
+
+int aipt_free(aipt_ctx* ctx, void* d_ptr) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, hipFree(d_ptr));
+    return AIPT_OK;
+}
+
+int aipt_upload(aipt_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_download(aipt_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_memset(aipt_ctx* ctx, void* d_dst, int value, size_t bytes) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_timer_start(aipt_ctx* ctx) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_timer_stop(aipt_ctx* ctx, float* ms_out) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    AIPT_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    AIPT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    if (ms_out) *ms_out = ms;
+    return AIPT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- frame
+static inline int round_up32(int v) { return (v + 31) & ~31; }
+
+int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
+    AIPT_CHECK_CTX(ctx);
+    if (width <= 0 || height <= 0) return fail(ctx, AIPT_E_INVALID, "aipt_frame_configure: %dx%d", width, height);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int wp = round_up32(width), hp = round_up32(height);   // pad policy: zeros bottom/right
+    int rc = aipt_trace_configure(ctx, width, height);
+    if (rc) return rc;
+    rc = aipt_denoise_configure(ctx, hp, wp);
+    if (rc) return rc;
+    if (ctx->d_gbuf) { hipFree(ctx->d_gbuf); ctx->d_gbuf = nullptr; }
+    if (ctx->d_out_pad) { hipFree(ctx->d_out_pad); ctx->d_out_pad = nullptr; }
+    const size_t plane = (size_t)wp * hp;
+    AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_gbuf, sizeof(float) * 10 * plane));
+    // a miss pixel is all-zero in the reference G-buffer; padding uses the same value and is never overwritten
+    AIPT_HIP(ctx, hipMemsetAsync(ctx->d_gbuf, 0, sizeof(float) * 10 * plane, ctx->stream));
+    if (wp != width || hp != height) AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_out_pad, sizeof(float) * 3 * plane));
+    ctx->fw = width; ctx->fh = height; ctx->fwp = wp; ctx->fhp = hp;
+    return AIPT_OK;
+}
+
+int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbuf) return fail(ctx, AIPT_E_STATE, "aipt_gbuffer: call aipt_frame_configure first");
+    if (d_gbuf) *d_gbuf = ctx->d_gbuf;
+    if (rows) *rows = ctx->fhp;
+    if (stride) *stride = ctx->fwp;
+    return AIPT_OK;
+}
+
+int aipt_frame_set_timing(aipt_ctx* ctx, int enabled) {
+    AIPT_CHECK_CTX(ctx);
+    ctx->frame_timing = enabled != 0;
+    ctx->frame_timed = false;
+    return AIPT_OK;
+}
+
+int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags, uint32_t dn_flags,
+               float* d_out3) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbuf) return fail(ctx, AIPT_E_STATE, "aipt_frame: call aipt_frame_configure first");
+    if (!cam || !d_out3) return fail(ctx, AIPT_E_INVALID, "aipt_frame: NULL argument");
+    if (cam->resolution[0] != ctx->fw || cam->resolution[1] != ctx->fh)
+        return fail(ctx, AIPT_E_INVALID, "aipt_frame: camera is %dx%d, configured %dx%d", cam->resolution[0],
+                    cam->resolution[1], ctx->fw, ctx->fh);
+    if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[0], ctx->stream));
+    int rc = aipt_trace(ctx, cam, iter, depth, trace_flags, ctx->d_gbuf, ctx->fhp, ctx->fwp);
+    if (rc) return rc;
+    if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
+    const bool crop = ctx->d_out_pad != nullptr;
+    rc = aipt_denoise(ctx, ctx->d_gbuf, crop ? ctx->d_out_pad : d_out3, dn_flags);
+    if (rc) return rc;
+    if (crop) {
+        // [3][hp][wp] -> [3][h][w]
+        AIPT_HIP(ctx, hipMemcpy2DAsync(d_out3, sizeof(float) * ctx->fw, ctx->d_out_pad, sizeof(float) * ctx->fwp,
+                                       sizeof(float) * ctx->fw, (size_t)ctx->fh, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int c = 1; c < 3; c++)
+            AIPT_HIP(ctx, hipMemcpy2DAsync(d_out3 + (size_t)c * ctx->fw * ctx->fh, sizeof(float) * ctx->fw,
+                                           ctx->d_out_pad + (size_t)c * ctx->fwp * ctx->fhp, sizeof(float) * ctx->fwp,
+                                           sizeof(float) * ctx->fw, (size_t)ctx->fh, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (ctx->frame_timing) {
+        AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
+        ctx->frame_timed = true;
+    }
+    return AIPT_OK;
+}
+
+int aipt_frame_last_times(aipt_ctx* ctx, float* trace_ms, float* denoise_ms) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->frame_timed) return fail(ctx, AIPT_E_STATE, "aipt_frame_last_times: no timed frame");
+    AIPT_HIP(ctx, hipEventSynchronize(ctx->fev[2]));
+    float a = 0, b = 0;
+    AIPT_HIP(ctx, hipEventElapsedTime(&a, ctx->fev[0], ctx->fev[1]));
+    AIPT_HIP(ctx, hipEventElapsedTime(&b, ctx->fev[1], ctx->fev[2]));
+    if (trace_ms) *trace_ms = a;
+    if (denoise_ms) *denoise_ms = b;
+    return AIPT_OK;
+}
+
+}  // extern "C"

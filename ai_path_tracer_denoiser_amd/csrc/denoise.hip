@@ -1,0 +1,707 @@
+// denoise.hip -- recurrent denoising auto-encoder forward pass on CDNA4 (gfx950), hand-written HIP.
+//
+// Replaces torch::jit::load + module.forward (reference Inference/src/main.cpp:104-111); the arithmetic is the model of
+// training/recurrent_autoencoder_model.py:8-142 (28 x conv3x3+bias, 28 x BatchNorm2d, LeakyReLU(0.1), 5 x MaxPool2d(2),
+// 5 x nearest Upsample x2, skip concats, 6 recurrent hidden states).
+//
+// Data layout in HBM: every activation is planar fp32 [C][h][w] (the G-buffer contract is planar, pathtrace.cu:81-94).
+// Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and
+// accumulates per-channel sum / sum-of-squares partials in its epilogue; a tiny finalize kernel turns them into a
+// per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a).  The CONSUMER applies x -> lrelu(a*x+b) while it
+// stages its input tile into LDS, so BatchNorm, LeakyReLU, channel concat (two source pointers) and nearest upsample
+// (source indexed at (y>>1, x>>1)) never touch HBM as separate passes.  Zero padding is applied in the normalised
+// domain (out-of-image taps load 0, not f(0)).  MaxPool needs normalised values, so one small pool kernel per encoder
+// level materialises the pooled, normalised skip tensor (quarter size).
+//
+// Hot kernel: conv3x3_mfma -- implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation; M = 16
+// consecutive pixels of a row, N = 16 output channels, K = 4 input channels of one filter tap), LDS-staged halo tile
+// and weight slab per 8-channel chunk.  Bound: fp32 MFMA peak (157.3 TFLOP/s); see DESIGN.md.
+#include "internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace aipt {
+
+constexpr int KC = 8;            // input channels per LDS chunk (2 MFMA k-steps)
+constexpr int NLAYERS = 28;
+constexpr float BN_EPS = 1e-5f;
+constexpr float SLOPE = 0.1f;
+
+static const int ENC_CH[5] = {32, 43, 57, 76, 101};
+static const int DEC_CH[6] = {0, 3, 32, 43, 57, 76};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvSrc {
+    const float* p;      // [C][sh][sw]
+    const float2* ab;    // per-channel affine, nullptr = identity
+    int C;
+    int up;              // 1: stored at half resolution, nearest-upsampled on load
+    float slope;         // LeakyReLU slope applied after the affine (1 = none)
+};
+
+struct ConvArgs {
+    ConvSrc a, b;        // channel concat: a's channels first
+    int H, W;            // conv (output) resolution
+    const float* w;      // [nchunks][9][KC][NP]
+    const float* w_raw;  // [cout][cin][3][3] (VALU cross-check kernel)
+    const float* bias;   // [NP]
+    int cin, cout, NP, nchunks;
+    float* out;          // [cout][H][W] raw
+    int out_lrelu;
+    float2* partial;     // [cout][nblk]
+    int nblk;
+};
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
+
+__device__ __forceinline__ float load_src(const ConvSrc& s, int ch, int y, int x, int H, int W) {
+    const int sh = s.up ? (H >> 1) : H, sw = s.up ? (W >> 1) : W;
+    const int sy = s.up ? (y >> 1) : y, sx = s.up ? (x >> 1) : x;
+    float v = s.p[((size_t)ch * sh + sy) * sw + sx];
+    if (s.ab) {
+        const float2 ab = s.ab[ch];
+        v = fmaf(ab.x, v, ab.y);
+    }
+    return lrelu(v, s.slope);
+}
+
+// -------------------------------------------------------------------------------------------------- MFMA conv
+// Block = 256 threads = 4 waves.  Tile = (4*RW) rows x (16*MBX) cols of output pixels x (16*NBB) output channels
+// (blockIdx.z selects the channel group).  Wave w owns rows [w*RW, w*RW+RW) of the tile.
+template <int RW, int MBX, int NBB>
+struct ConvCfg {
+    static constexpr int TH = 4 * RW, TW = 16 * MBX;
+    static constexpr int RS = TW + 2;                               // LDS row stride of the halo tile
+    static constexpr int CS0 = (TH + 2) * RS;
+    static constexpr int CS = CS0 + ((16 - (CS0 % 32)) + 32) % 32;  // channel stride == 16 (mod 32): k and k+1 hit disjoint banks
+    static constexpr int NPB0 = 16 * NBB;
+    static constexpr int NPB = NPB0 + ((16 - (NPB0 % 32)) + 32) % 32;
+    static constexpr int A_FLOATS = KC * CS;
+    static constexpr int B_FLOATS = 9 * KC * NPB;
+};
+
+template <int RW, int MBX, int NBB>
+__global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs g) {
+    using Cfg = ConvCfg<RW, MBX, NBB>;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, RS = Cfg::RS, CS = Cfg::CS, NPB = Cfg::NPB;
+    __shared__ __attribute__((aligned(16))) float smem[Cfg::A_FLOATS + Cfg::B_FLOATS];
+    float* As = smem;
+    float* Bs = smem + Cfg::A_FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int n0 = blockIdx.z * NBB * 16;      // first output channel of this block
+    const int H = g.H, W = g.W;
+    const int lk = lane >> 4, li = lane & 15;
+
+    f32x4 acc[RW][MBX][NBB];
+#pragma unroll
+    for (int r = 0; r < RW; r++)
+#pragma unroll
+        for (int m = 0; m < MBX; m++)
+#pragma unroll
+            for (int n = 0; n < NBB; n++) acc[r][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ctot = g.a.C + g.b.C;
+    for (int chunk = 0; chunk < g.nchunks; chunk++) {
+        __syncthreads();
+        // ---- stage the halo tile of KC input channels, applying the producer's pending BN affine + LReLU
+        for (int e = tid; e < KC * (TH + 2) * RS; e += 256) {
+            const int c = e / ((TH + 2) * RS);
+            const int rem = e - c * ((TH + 2) * RS);
+            const int yy = rem / RS, xx = rem - yy * RS;
+            const int y = ty0 + yy - 1, x = tx0 + xx - 1;
+            const int cg = chunk * KC + c;
+            float v = 0.0f;
+            if (cg < ctot && y >= 0 && y < H && x >= 0 && x < W)
+                v = cg < g.a.C ? load_src(g.a, cg, y, x, H, W) : load_src(g.b, cg - g.a.C, y, x, H, W);
+            As[c * CS + yy * RS + xx] = v;
+        }
+        // ---- stage the weight slab [9][KC][NBB*16] of this chunk / channel group
+        {
+            const float* wsrc = g.w + (size_t)chunk * 9 * KC * g.NP + n0;
+            constexpr int ROWF4 = NBB * 4;                 // float4 per (tap,kc) row
+            for (int e = tid; e < 9 * KC * ROWF4; e += 256) {
+                const int row = e / ROWF4, q = e - row * ROWF4;
+                const float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)row * g.NP + q * 4);
+                *reinterpret_cast<float4*>(Bs + row * NPB + q * 4) = v;
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x 2 k-steps of v_mfma_f32_16x16x4_f32
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int ks = 0; ks < KC / 4; ks++) {
+                float bf[NBB];
+#pragma unroll
+                for (int n = 0; n < NBB; n++) bf[n] = Bs[(tap * KC + ks * 4 + lk) * NPB + n * 16 + li];
+#pragma unroll
+                for (int r = 0; r < RW; r++) {
+                    const float* arow = As + (ks * 4 + lk) * CS + (wave * RW + r + ky) * RS + li + kx;
+#pragma unroll
+                    for (int m = 0; m < MBX; m++) {
+                        const float af = arow[m * 16];
+#pragma unroll
+                        for (int n = 0; n < NBB; n++)
+                            acc[r][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[n], acc[r][m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: bias (+LReLU), store raw output, per-channel sum / sum-of-squares partials
+    // D fragment: register q of lane l holds pixel 4*(l>>4)+q of the 16-pixel block, output channel l&15.
+    float s1[NBB], s2[NBB];
+#pragma unroll
+    for (int n = 0; n < NBB; n++) { s1[n] = 0.f; s2[n] = 0.f; }
+    const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+    for (int n = 0; n < NBB; n++) {
+        const int j = n0 + n * 16 + li;
+        const bool jok = j < g.cout;
+        const float bj = g.bias[n0 + n * 16 + li];
+#pragma unroll
+        for (int r = 0; r < RW; r++) {
+            const int y = ty0 + wave * RW + r;
+#pragma unroll
+            for (int m = 0; m < MBX; m++) {
+                const int xb = tx0 + m * 16 + lk * 4;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float t = acc[r][m][n][q] + bj;
+                    if (g.out_lrelu) t = lrelu(t, SLOPE);
+                    v[q] = t;
+                }
+                if (jok && y < H) {
+                    float* o = g.out + ((size_t)j * H + y) * W + xb;
+                    if (vec_ok && xb + 3 < W) {
+                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { s1[n] += v[q]; s2[n] += v[q] * v[q]; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (xb + q < W) { o[q] = v[q]; s1[n] += v[q]; s2[n] += v[q] * v[q]; }
+                    }
+                }
+            }
+        }
+    }
+    if (g.partial) {
+        __syncthreads();                        // everyone is done with As/Bs
+        float2* red = reinterpret_cast<float2*>(smem);     // [4 waves][NBB*16]
+#pragma unroll
+        for (int n = 0; n < NBB; n++) {
+            float a = s1[n], b = s2[n];
+            a += __shfl_xor(a, 16); b += __shfl_xor(b, 16);
+            a += __shfl_xor(a, 32); b += __shfl_xor(b, 32);
+            if (lk == 0) red[wave * (NBB * 16) + n * 16 + li] = make_float2(a, b);
+        }
+        __syncthreads();
+        if (tid < NBB * 16) {
+            const int j = n0 + tid;
+            if (j < g.cout) {
+                float2 t = red[tid];
+                for (int w = 1; w < 4; w++) { t.x += red[w * (NBB * 16) + tid].x; t.y += red[w * (NBB * 16) + tid].y; }
+                g.partial[(size_t)j * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- VALU conv
+// One thread per output element; reads its 9*cin taps straight from HBM.  Only for on-GPU cross-checks.
+__global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y, j = blockIdx.z;
+    if (x >= g.W) return;
+    float acc = g.bias[j];
+    const int ctot = g.a.C + g.b.C;
+    for (int c = 0; c < ctot; c++) {
+        const float* wk = g.w_raw + ((size_t)j * g.cin + c) * 9;
+        for (int ky = 0; ky < 3; ky++)
+            for (int kx = 0; kx < 3; kx++) {
+                const int yy = y + ky - 1, xx = x + kx - 1;
+                if (yy < 0 || yy >= g.H || xx < 0 || xx >= g.W) continue;
+                const float v = c < g.a.C ? load_src(g.a, c, yy, xx, g.H, g.W) : load_src(g.b, c - g.a.C, yy, xx, g.H, g.W);
+                acc = fmaf(v, wk[ky * 3 + kx], acc);
+            }
+    }
+    if (g.out_lrelu) acc = lrelu(acc, SLOPE);
+    g.out[((size_t)j * g.H + y) * g.W + x] = acc;
+}
+
+// per-channel sum / sum-of-squares of a stored tensor (VALU path only): one block per channel
+__global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, float2* partial) {
+    const float* p = t + (size_t)blockIdx.x * hw;
+    double a = 0, b = 0;
+    for (size_t i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; a += v; b += v * v; }
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = make_float2((float)sa[0], (float)sb[0]);
+}
+
+// -------------------------------------------------------------------------------------------------- BN finalize
+// One block per channel: fixed-order fp64 tree over the conv blocks' partials -> (a, b).  running != nullptr copies
+// the precomputed running-statistics affine instead.
+__global__ __launch_bounds__(256) void bn_finalize(const float2* partial, int nblk, double inv_n, const float* gamma,
+                                                   const float* beta, const float2* running, float2* ab) {
+    const int c = blockIdx.x;
+    if (running) {
+        if (threadIdx.x == 0) ab[c] = running[c];
+        return;
+    }
+    double a = 0, b = 0;
+    for (int i = threadIdx.x; i < nblk; i += 256) {
+        const float2 p = partial[(size_t)c * nblk + i];
+        a += p.x; b += p.y;
+    }
+    __shared__ double sa[256], sb[256];
+    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sa[0] * inv_n;
+        double var = sb[0] * inv_n - mean * mean;      // biased variance, as torch normalises with
+        if (var < 0) var = 0;
+        const double sc = (double)gamma[c] / sqrt(var + (double)BN_EPS);
+        ab[c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- elementwise
+// out[c][y][x] = max over the 2x2 block of lrelu(a*raw+b): MaxPool2d(2) of the normalised tensor.
+__global__ __launch_bounds__(256) void pool2_norm(const float* raw, const float2* ab, float slope, int C, int H, int W,
+                                                  float* out) {
+    const int h = H >> 1, w = W >> 1;
+    const size_t n = (size_t)C * h * w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const size_t t = i / w;
+        const int y = (int)(t % h), c = (int)(t / h);
+        const float2 f = ab[c];
+        const float* p = raw + ((size_t)c * H + 2 * y) * W + 2 * x;
+        const float2 r0 = *reinterpret_cast<const float2*>(p);
+        const float2 r1 = *reinterpret_cast<const float2*>(p + W);
+        const float v0 = lrelu(fmaf(f.x, r0.x, f.y), slope), v1 = lrelu(fmaf(f.x, r0.y, f.y), slope);
+        const float v2 = lrelu(fmaf(f.x, r1.x, f.y), slope), v3 = lrelu(fmaf(f.x, r1.y, f.y), slope);
+        out[i] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+    }
+}
+
+// out = lrelu(a*raw+b) (network output, hidden-state export)
+__global__ __launch_bounds__(256) void apply_norm(const float* raw, const float2* ab, float slope, int C, size_t hw,
+                                                  float* out) {
+    const size_t n = (size_t)C * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float2 f = ab[i / hw];
+        out[i] = lrelu(fmaf(f.x, raw[i], f.y), slope);
+    }
+}
+
+__global__ void fill_ab_identity(float2* ab, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) ab[i] = make_float2(1.0f, 0.0f);
+}
+
+// -------------------------------------------------------------------------------------------------- host side
+struct LayerW {
+    int cin = 0, cout = 0, NB = 0, NP = 0, nchunks = 0;
+    float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
+    float2* d_ab_running = nullptr;
+};
+
+struct Tensor {
+    float* p = nullptr;
+    float2* ab = nullptr;
+    int C = 0;
+    float slope = SLOPE;
+};
+
+struct DenoiseState {
+    bool have_weights = false;
+    LayerW L[NLAYERS];
+    int H = 0, W = 0;
+    Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
+    Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
+    Tensor D1[6], D2[6];           // decoder k = 1..5
+    float2* partial = nullptr;
+    size_t partial_elems = 0;
+    bool hidden_valid = false;
+    int impl = AIPT_DN_IMPL_MFMA;
+    std::vector<void*> allocs;
+};
+
+static void build_table(int* cin, int* cout) {
+    int n = 0, c_in = 10;
+    for (int i = 0; i < 5; i++) {
+        const int c = ENC_CH[i];
+        cin[n] = c_in;  cout[n++] = c;
+        cin[n] = 2 * c; cout[n++] = c;
+        cin[n] = c;     cout[n++] = c;
+        c_in = c;
+    }
+    cin[n] = 101; cout[n++] = 101;
+    cin[n] = 202; cout[n++] = 101;
+    cin[n] = 101; cout[n++] = 101;
+    int prev = 101;
+    for (int k = 5; k >= 1; k--) {
+        cin[n] = prev + ENC_CH[k - 1]; cout[n++] = DEC_CH[k];
+        cin[n] = DEC_CH[k];            cout[n++] = DEC_CH[k];
+        prev = DEC_CH[k];
+    }
+}
+
+static void free_weights(DenoiseState* s) {
+    for (auto& l : s->L) {
+        hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
+        hipFree(l.d_ab_running);
+        l = LayerW();
+    }
+    s->have_weights = false;
+}
+
+static void free_activations(DenoiseState* s) {
+    for (void* p : s->allocs) hipFree(p);
+    s->allocs.clear();
+    s->partial = nullptr;
+    s->H = s->W = 0;
+}
+
+void denoise_destroy(aipt_ctx* ctx) {
+    if (!ctx->dn) return;
+    free_weights(ctx->dn);
+    free_activations(ctx->dn);
+    delete ctx->dn;
+    ctx->dn = nullptr;
+}
+
+static DenoiseState* state(aipt_ctx* ctx) {
+    if (!ctx->dn) ctx->dn = new DenoiseState();
+    return ctx->dn;
+}
+
+template <int RW, int MBX, int NBB>
+static void launch_mfma(const ConvArgs& a, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv3x3_mfma<RW, MBX, NBB>), grid, dim3(256), 0, st, a);
+}
+
+struct TileChoice { int rw, mbx, nbb; };
+
+// Pick the tile so that the launch has enough workgroups for 256 CUs (MI355X): big tiles for the full-resolution
+// levels, narrow channel groups and small tiles for the deep, low-resolution levels.
+static TileChoice choose_tile(int H, int W, int NB) {
+    auto blocks = [&](int rw, int mbx, int nbb) {
+        return (long)((W + 16 * mbx - 1) / (16 * mbx)) * ((H + 4 * rw - 1) / (4 * rw)) * (NB / nbb);
+    };
+    if (NB <= 3 && blocks(2, 2, NB) >= 512) return {2, 2, NB};
+    const int cand[][3] = {{1, 2, 3}, {1, 2, 2}, {1, 2, 1}, {1, 1, 1}};
+    TileChoice best = {1, 1, 1};
+    long bestb = -1;
+    for (auto& c : cand) {
+        if (NB % c[2]) continue;
+        const long b = blocks(c[0], c[1], c[2]);
+        if (b >= 400) return {c[0], c[1], c[2]};
+        if (b > bestb) { bestb = b; best = {c[0], c[1], c[2]}; }
+    }
+    return best;
+}
+
+static int conv_nblk(const TileChoice& t, int H, int W) {
+    return ((W + 16 * t.mbx - 1) / (16 * t.mbx)) * ((H + 4 * t.rw - 1) / (4 * t.rw));
+}
+
+// conv + (stats ->) finalize.  `dst` receives the raw output and its (a,b).
+static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
+                    int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b) {
+    const LayerW& L = s->L[li];
+    ConvArgs g;
+    g.a = ConvSrc{A.p, A.ab, A.C, upA, A.slope};
+    if (B && use_b) g.b = ConvSrc{B->p, B->ab, B->C, upB, B->slope};
+    else g.b = ConvSrc{nullptr, nullptr, 0, 0, 1.0f};
+    g.H = H; g.W = W;
+    g.w = L.d_w; g.w_raw = L.d_w_raw; g.bias = L.d_bias;
+    g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
+    g.nchunks = (g.a.C + g.b.C + KC - 1) / KC;
+    g.out = dst.p; g.out_lrelu = out_lrelu;
+    const int expect = A.C + (B ? B->C : 0);
+    if (expect != L.cin) return fail(ctx, AIPT_E_STATE, "layer %d: %d input channels wired, %d expected", li, expect, L.cin);
+    int nblk = 1;
+    if (s->impl == AIPT_DN_IMPL_VALU) {
+        g.partial = nullptr; g.nblk = 1;
+        hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
+        if (batch)
+            hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, s->partial);
+    } else {
+        const TileChoice t = choose_tile(H, W, L.NB);
+        nblk = conv_nblk(t, H, W);
+        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        g.partial = batch ? s->partial : nullptr;
+        g.nblk = nblk;
+        const dim3 grid((W + 16 * t.mbx - 1) / (16 * t.mbx), (H + 4 * t.rw - 1) / (4 * t.rw), L.NB / t.nbb);
+        const int key = t.rw * 100 + t.mbx * 10 + t.nbb;
+        switch (key) {
+            case 221: launch_mfma<2, 2, 1>(g, grid, ctx->stream); break;
+            case 222: launch_mfma<2, 2, 2>(g, grid, ctx->stream); break;
+            case 223: launch_mfma<2, 2, 3>(g, grid, ctx->stream); break;
+            case 121: launch_mfma<1, 2, 1>(g, grid, ctx->stream); break;
+            case 122: launch_mfma<1, 2, 2>(g, grid, ctx->stream); break;
+            case 123: launch_mfma<1, 2, 3>(g, grid, ctx->stream); break;
+            case 111: launch_mfma<1, 1, 1>(g, grid, ctx->stream); break;
+            default: return fail(ctx, AIPT_E_STATE, "no conv instantiation for tile %d", key);
+        }
+    }
+    hipLaunchKernelGGL(bn_finalize, dim3(L.cout), dim3(256), 0, ctx->stream, s->partial, nblk,
+                       1.0 / ((double)H * (double)W), L.d_gamma, L.d_beta, batch ? nullptr : L.d_ab_running, dst.ab);
+    AIPT_HIP(ctx, hipGetLastError());
+    return AIPT_OK;
+}
+
+}  // namespace aipt
+
+using namespace aipt;
+
+extern "C" {
+
+int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
+    AIPT_CHECK_CTX(ctx);
+    if (!blob) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_load_weights: blob is NULL");
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint8_t* p = (const uint8_t*)blob;
+    if (bytes < 16 || memcmp(p, "AIPTDW01", 8)) return fail(ctx, AIPT_E_FORMAT, "weight blob: bad magic");
+    uint32_t n; memcpy(&n, p + 8, 4);
+    if (n != NLAYERS) return fail(ctx, AIPT_E_FORMAT, "weight blob: %u layers, expected %d", n, NLAYERS);
+    int cin[NLAYERS], cout[NLAYERS];
+    build_table(cin, cout);
+    size_t off = 16, nfl = 0;
+    if (bytes < off + 8 * NLAYERS) return fail(ctx, AIPT_E_FORMAT, "weight blob: truncated header");
+    for (int i = 0; i < NLAYERS; i++) {
+        uint32_t ci, co; memcpy(&ci, p + off, 4); memcpy(&co, p + off + 4, 4); off += 8;
+        if ((int)ci != cin[i] || (int)co != cout[i])
+            return fail(ctx, AIPT_E_FORMAT, "weight blob: layer %d is %ux%u, expected %dx%d", i, ci, co, cin[i], cout[i]);
+        nfl += (size_t)9 * ci * co + 5 * (size_t)co;
+    }
+    if (off + 4 * nfl != bytes) return fail(ctx, AIPT_E_FORMAT, "weight blob: %zu bytes, expected %zu", bytes, off + 4 * nfl);
+    DenoiseState* s = state(ctx);
+    free_weights(s);
+    std::vector<float> f(nfl);
+    memcpy(f.data(), p + off, 4 * nfl);
+    const float* q = f.data();
+    for (int i = 0; i < NLAYERS; i++) {
+        LayerW& L = s->L[i];
+        L.cin = cin[i]; L.cout = cout[i];
+        L.NB = (L.cout + 15) / 16; L.NP = L.NB * 16;
+        L.nchunks = (L.cin + KC - 1) / KC;
+        const float* w = q;          q += (size_t)9 * L.cin * L.cout;
+        const float* b = q;          q += L.cout;
+        const float* gamma = q;      q += L.cout;
+        const float* beta = q;       q += L.cout;
+        const float* mean = q;       q += L.cout;
+        const float* var = q;        q += L.cout;
+        // implicit-GEMM layout: [chunk][tap][kc][NP], zero padded in both cin and cout
+        std::vector<float> wg((size_t)L.nchunks * 9 * KC * L.NP, 0.0f);
+        for (int j = 0; j < L.cout; j++)
+            for (int c = 0; c < L.cin; c++)
+                for (int t = 0; t < 9; t++)
+                    wg[(((size_t)(c / KC) * 9 + t) * KC + (c % KC)) * L.NP + j] = w[((size_t)j * L.cin + c) * 9 + t];
+        std::vector<float> bp(L.NP, 0.0f);
+        memcpy(bp.data(), b, 4 * L.cout);
+        std::vector<float2> abr(L.cout);
+        for (int j = 0; j < L.cout; j++) {
+            const double sc = (double)gamma[j] / sqrt((double)var[j] + (double)BN_EPS);
+            abr[j] = make_float2((float)sc, (float)((double)beta[j] - (double)mean[j] * sc));
+        }
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_w, wg.size() * 4));
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_w_raw, (size_t)9 * L.cin * L.cout * 4));
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias, L.NP * 4));
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_gamma, L.cout * 4));
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_beta, L.cout * 4));
+        AIPT_HIP(ctx, hipMalloc((void**)&L.d_ab_running, L.cout * sizeof(float2)));
+        AIPT_HIP(ctx, hipMemcpy(L.d_w, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(L.d_w_raw, w, (size_t)9 * L.cin * L.cout * 4, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(L.d_bias, bp.data(), L.NP * 4, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(L.d_gamma, gamma, L.cout * 4, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(L.d_beta, beta, L.cout * 4, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(L.d_ab_running, abr.data(), L.cout * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    s->have_weights = true;
+    return AIPT_OK;
+}
+
+int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
+    AIPT_CHECK_CTX(ctx);
+    if (height <= 0 || width <= 0 || (height % 32) || (width % 32))
+        return fail(ctx, AIPT_E_INVALID, "aipt_denoise_configure: %dx%d is not a positive multiple of 32 "
+                    "(5 x MaxPool2d(2) + skip concat, recurrent_autoencoder_model.py:98-107,136-140)", height, width);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    DenoiseState* s = state(ctx);
+    if (s->H == height && s->W == width) return AIPT_OK;
+    free_activations(s);
+    auto alloc = [&](size_t bytes, void** out) -> int {
+        AIPT_HIP(ctx, hipMalloc(out, bytes));
+        s->allocs.push_back(*out);
+        return AIPT_OK;
+    };
+    auto mk = [&](Tensor& t, int C, int lvl) -> int {
+        t.C = C; t.slope = SLOPE;
+        int rc = alloc(sizeof(float) * (size_t)C * (height >> lvl) * (width >> lvl), (void**)&t.p);
+        if (rc) return rc;
+        rc = alloc(sizeof(float2) * C, (void**)&t.ab);
+        if (rc) return rc;
+        hipLaunchKernelGGL(fill_ab_identity, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, C);
+        return AIPT_OK;
+    };
+    int rc = 0;
+    for (int i = 0; i < 6 && !rc; i++) {
+        const int c = i < 5 ? ENC_CH[i] : 101;
+        rc = mk(s->T1[i], c, i);
+        if (!rc) rc = mk(s->T2[i], c, i);
+        if (!rc) rc = mk(s->Hid[i], c, i);
+        if (!rc && i < 5) { rc = mk(s->P[i], c, i + 1); s->P[i].slope = 1.0f; }
+    }
+    for (int k = 1; k <= 5 && !rc; k++) {
+        rc = mk(s->D1[k], DEC_CH[k], k - 1);
+        if (!rc) rc = mk(s->D2[k], DEC_CH[k], k - 1);
+    }
+    if (rc) { free_activations(s); return rc; }
+    // partial sums: cout x (#pixel tiles) for the finest tiling used (4 x 16 pixels)
+    size_t mx = 0;
+    for (int lvl = 0; lvl < 6; lvl++) {
+        const int h = height >> lvl, w = width >> lvl;
+        const size_t tiles = (size_t)((w + 15) / 16) * ((h + 3) / 4);
+        const int c = lvl < 5 ? ENC_CH[lvl] : 101;
+        if (tiles * c > mx) mx = tiles * c;
+    }
+    rc = alloc(sizeof(float2) * mx, (void**)&s->partial);
+    if (rc) { free_activations(s); return rc; }
+    s->partial_elems = mx;
+    s->H = height; s->W = width;
+    s->hidden_valid = false;
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AIPT_OK;
+}
+
+int aipt_denoise_set_impl(aipt_ctx* ctx, int impl) {
+    AIPT_CHECK_CTX(ctx);
+    if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
+    state(ctx)->impl = impl;
+    return AIPT_OK;
+}
+
+int aipt_denoise_reset_hidden(aipt_ctx* ctx) {
+    AIPT_CHECK_CTX(ctx);
+    state(ctx)->hidden_valid = false;
+    return AIPT_OK;
+}
+
+int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
+    if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise: call aipt_denoise_configure first");
+    if (!d_in10 || !d_out3) return fail(ctx, AIPT_E_INVALID, "aipt_denoise: NULL buffer");
+    const bool batch = (flags & AIPT_DN_BN_BATCH) != 0;
+    const bool carry = (flags & AIPT_DN_HIDDEN_CARRY) != 0 && s->hidden_valid;
+    const int H = s->H, W = s->W;
+    int li = 0, rc = 0;
+    Tensor in;
+    in.p = const_cast<float*>(d_in10); in.ab = nullptr; in.C = 10; in.slope = 1.0f;
+    const Tensor* x = &in;
+    // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
+    for (int i = 0; i < 5; i++) {
+        const int h = H >> i, w = W >> i;
+        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, s->T1[i], batch, false))) return rc;
+        if ((rc = run_conv(ctx, s, li++, s->T1[i], 0, &s->Hid[i], 0, h, w, 1, s->T2[i], batch, carry))) return rc;
+        Tensor t2 = s->T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
+        if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, s->Hid[i], batch, false))) return rc;
+        s->Hid[i].slope = SLOPE;
+        const size_t n = (size_t)ENC_CH[i] * (h / 2) * (w / 2);
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(pool2_norm, dim3(grid), dim3(256), 0, ctx->stream, s->Hid[i].p, s->Hid[i].ab, SLOPE,
+                           ENC_CH[i], h, w, s->P[i].p);
+        x = &s->P[i];
+    }
+    {   // bottleneck: conv-BN-LReLU three times
+        const int h = H >> 5, w = W >> 5;
+        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, s->T1[5], batch, false))) return rc;
+        if ((rc = run_conv(ctx, s, li++, s->T1[5], 0, &s->Hid[5], 0, h, w, 0, s->T2[5], batch, carry))) return rc;
+        if ((rc = run_conv(ctx, s, li++, s->T2[5], 0, nullptr, 0, h, w, 0, s->Hid[5], batch, false))) return rc;
+        s->Hid[5].slope = SLOPE;
+    }
+    // decoders: cat(prev, skip) -> Upsample x2 -> conv BN LReLU conv BN LReLU
+    const Tensor* prev = &s->Hid[5];
+    for (int k = 5; k >= 1; k--) {
+        const int h = H >> (k - 1), w = W >> (k - 1);
+        if ((rc = run_conv(ctx, s, li++, *prev, 1, &s->P[k - 1], 1, h, w, 0, s->D1[k], batch, true))) return rc;
+        if ((rc = run_conv(ctx, s, li++, s->D1[k], 0, nullptr, 0, h, w, 0, s->D2[k], batch, false))) return rc;
+        prev = &s->D2[k];
+    }
+    {
+        const size_t n = (size_t)3 * H * W;
+        const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        hipLaunchKernelGGL(apply_norm, dim3(grid), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].ab, SLOPE, 3,
+                           (size_t)H * W, d_out3);
+    }
+    AIPT_HIP(ctx, hipGetLastError());
+    s->hidden_valid = true;
+    return li == NLAYERS ? AIPT_OK : fail(ctx, AIPT_E_STATE, "aipt_denoise: ran %d layers", li);
+}
+
+int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise_get_hidden: not configured");
+    if (level < 0 || level > 5 || !d_dst) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_get_hidden: level %d", level);
+    const Tensor& t = s->Hid[level];
+    const size_t hw = (size_t)(s->H >> level) * (s->W >> level);
+    if (!s->hidden_valid) {
+        AIPT_HIP(ctx, hipMemsetAsync(d_dst, 0, sizeof(float) * t.C * hw, ctx->stream));
+        return AIPT_OK;
+    }
+    const size_t n = t.C * hw;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(apply_norm, dim3(grid), dim3(256), 0, ctx->stream, t.p, t.ab, t.slope, t.C, hw, d_dst);
+    AIPT_HIP(ctx, hipGetLastError());
+    return AIPT_OK;
+}
+
+int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise_set_hidden: not configured");
+    if (level < 0 || level > 5 || !d_src) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_hidden: level %d", level);
+    Tensor& t = s->Hid[level];
+    const size_t hw = (size_t)(s->H >> level) * (s->W >> level);
+    if (!s->hidden_valid) {
+        // the other levels must read as zeros: raw 0 with identity transform
+        for (int l = 0; l < 6; l++) {
+            Tensor& o = s->Hid[l];
+            AIPT_HIP(ctx, hipMemsetAsync(o.p, 0, sizeof(float) * o.C * (size_t)(s->H >> l) * (s->W >> l), ctx->stream));
+            hipLaunchKernelGGL(fill_ab_identity, dim3((o.C + 63) / 64), dim3(64), 0, ctx->stream, o.ab, o.C);
+            o.slope = 1.0f;
+        }
+        s->hidden_valid = true;
+    }
+    AIPT_HIP(ctx, hipMemcpyAsync(t.p, d_src, sizeof(float) * t.C * hw, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(fill_ab_identity, dim3((t.C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, t.C);
+    t.slope = 1.0f;      // already normalised: no LReLU on load
+    AIPT_HIP(ctx, hipGetLastError());
+    return AIPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+/*
+ * aiptd.h -- C ABI of the MI355X-native 1-spp path-trace + recurrent-denoise hot path.
+ *
+ * Drop-in boundary for the reference's hot path (paths relative to /root/reference/Inference):
+ *
+ *   reference interface                                            replaced by
+ *   -------------------------------------------------------------  -----------------------------------------
+ *   void pathtraceInit(Scene*)              src/pathtrace.h:6      aipt_scene_upload + aipt_trace_configure
+ *   void pathtraceFree()                    src/pathtrace.h:7      aipt_scene_free / aipt_destroy
+ *   void pathtrace(uchar4*, int, int)       src/pathtrace.h:8      aipt_trace
+ *   scene->state.host_tensor (float[10*W*H]) src/sceneStructs.h:74 the device G-buffer (aipt_gbuffer) /
+ *        filled by cudaMemcpy D2H           src/pathtrace.cu:525   aipt_download when a host copy is wanted
+ *   torch::jit::load(MODEL_PATH)            src/main.cpp:107       aipt_denoise_load_weights
+ *   module.forward({[1,10,W,H]}) -> [1,3,W,H] src/main.cpp:104-111 aipt_denoise
+ *   runCuda() per-frame body                src/main.cpp:143-163   aipt_frame
+ *   Scene::Scene(filename)                  src/scene.cpp:11-42    aipt_scene_load (host-side front end)
+ *
+ * The POD structs below have the byte layout of the reference's sceneStructs.h types (glm::vec3 = 3 floats,
+ * glm::mat4 = 16 floats column-major), so a reference-side caller can pass scene->geoms.data() etc. directly
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions: every function returns AIPT_OK (0) or a negative AIPT_E_* code; aipt_last_error() gives the message.
+ * No C++ exception crosses this boundary.  One context per GPU and per host thread; all work is enqueued on the
+ * context's HIP stream and is asynchronous unless stated otherwise.  Pointers named d_* are device pointers.
+ * There is no CPU fallback: without a usable HIP device aipt_create fails.
+ */
+#ifndef AIPTD_H
+#define AIPTD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIPT_ABI_VERSION 1
+
+#define AIPT_OK          0
+#define AIPT_E_INVALID  -1   /* bad argument */
+#define AIPT_E_HIP      -2   /* HIP runtime error */
+#define AIPT_E_STATE    -3   /* call out of order (e.g. trace before scene upload) */
+#define AIPT_E_NOMEM    -4
+#define AIPT_E_FORMAT   -5   /* malformed weight blob / scene file */
+#define AIPT_E_IO       -6
+
+typedef struct aipt_ctx aipt_ctx;
+
+/* sceneStructs.h:8-13 */
+#define AIPT_GEOM_SPHERE 0
+#define AIPT_GEOM_CUBE   1
+
+typedef struct aipt_geom {            /* Geom, sceneStructs.h:20-30, 248 bytes */
+    int type;
+    int materialid;
+    float translation[3];
+    float rotation[3];
+    float scale[3];
+    float transform[16];              /* column-major */
+    float inverseTransform[16];
+    float invTranspose[16];
+    float vel[3];
+} aipt_geom;
+
+typedef struct aipt_face {            /* Face, sceneStructs.h:40-44, 76 bytes */
+    float v[3][3];
+    float n[3][3];
+    int materialid;
+} aipt_face;
+
+typedef struct aipt_material {        /* Material, sceneStructs.h:46-56, 44 bytes */
+    float color[3];
+    float specular_exponent;
+    float specular_color[3];
+    float hasReflective;
+    float hasRefractive;
+    float indexOfRefraction;
+    float emittance;
+} aipt_material;
+
+typedef struct aipt_camera {          /* Camera, sceneStructs.h:58-67, 84 bytes */
+    int resolution[2];                /* x = width, y = height */
+    float position[3];
+    float lookAt[3];
+    float view[3];
+    float up[3];
+    float right[3];
+    float fov[2];
+    float pixelLength[2];
+} aipt_camera;
+
+typedef struct aipt_aabb {            /* MeshBoundingBox, sceneStructs.h:84-87, 24 bytes */
+    float lb[3];
+    float ub[3];
+} aipt_aabb;
+
+/* ---- context ---------------------------------------------------------------------------------------------- */
+/* stream: an existing hipStream_t to enqueue on (e.g. the caller's torch stream), or NULL to create one. */
+int  aipt_create(int device, void* stream, aipt_ctx** out);
+void aipt_destroy(aipt_ctx* ctx);
+const char* aipt_last_error(const aipt_ctx* ctx);      /* ctx may be NULL: error of the last failed aipt_create */
+int  aipt_abi_version(void);
+int  aipt_sync(aipt_ctx* ctx);                          /* hipStreamSynchronize on the context stream */
+
+/* device memory helpers for hosts that do not link HIP themselves */
+int  aipt_malloc(aipt_ctx* ctx, size_t bytes, void** d_out);
+int  aipt_free(aipt_ctx* ctx, void* d_ptr);
+int  aipt_upload(aipt_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);      /* synchronous */
+int  aipt_download(aipt_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);    /* synchronous */
+int  aipt_memset(aipt_ctx* ctx, void* d_dst, int value, size_t bytes);              /* async */
+/* HIP-event timer on the context stream (bench.py's roofline leg): start, ..., stop -> elapsed ms (stop syncs) */
+int  aipt_timer_start(aipt_ctx* ctx);
+int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
+
+/* ---- path trace (pathtrace.h:6-8) ------------------------------------------------------------------------- */
+#define AIPT_TRACE_AA          1u   /* jitter primary rays (AA true, pathtrace.cu:25) */
+#define AIPT_TRACE_COMPACT     2u   /* stream-compaction semantics (STREAM_COMPACTION true, pathtrace.cu:20): the RNG of
+                                       bounce b is seeded with the path's rank among the live paths, as thrust::partition
+                                       leaves it (pathtrace.cu:351,505).  Without it the seed index is the pixel index. */
+#define AIPT_TRACE_RECORD_MAT0 4u   /* also record the first-hit material id per pixel (integer parity channel) */
+#define AIPT_TRACE_DEFAULT     (AIPT_TRACE_AA | AIPT_TRACE_COMPACT)
+
+/* pathtraceInit (pathtrace.cu:96-129), scene part: copies and re-lays-out the scene on the device.
+ * faces/mesh_box may be NULL when nfaces == 0. */
+int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
+                      const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box);
+int aipt_scene_free(aipt_ctx* ctx);                      /* pathtraceFree (pathtrace.cu:131-145) */
+/* pathtraceInit, frame-size part: path-state buffers for width x height pixels (allocated once, not per frame). */
+int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
+/* pathtrace (pathtrace.cu:422-528), one 1-spp iteration.  d_gbuf is float[10][gbuf_rows][gbuf_stride] with
+ * gbuf_rows >= height and gbuf_stride >= width; the 10 planes are: 0-2 radiance/iter, 3-5 first-hit normal, 6 first-hit
+ * distance, 7-9 first-bounce albedo, horizontally flipped exactly as copy_data / computeIntersections write them
+ * (pathtrace.cu:81-94, 295-304, 379-387).  Every in-frame element is written each call; padding is left untouched. */
+int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
+               float* d_gbuf, int gbuf_rows, int gbuf_stride);
+/* live-path counts of the last aipt_trace: n_live[b] = paths entering bounce b, b = 0..depth (synchronous). */
+int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n);
+/* first-hit material ids (-1 = miss) per pixel index of the last AIPT_TRACE_RECORD_MAT0 trace (synchronous). */
+int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n);
+
+/* ---- denoiser (main.cpp:101-118; model = training/recurrent_autoencoder_model.py) --------------------------- */
+#define AIPT_DN_BN_BATCH      1u    /* BatchNorm with statistics of the current frame: what the reference's shipped
+                                       TorchScript computes (traced in train mode, convert_to_torchscript.py:26-30) */
+#define AIPT_DN_BN_RUNNING    0u    /* BatchNorm with the stored running statistics (model.eval(), training/test.py:35) */
+#define AIPT_DN_HIDDEN_CARRY  2u    /* carry the six recurrent hidden states from the previous call (forward(x, j>0)) */
+#define AIPT_DN_HIDDEN_RESET  0u    /* zero hidden state (forward(x, j=0), recurrent_autoencoder_model.py:121-128) */
+
+#define AIPT_DN_IMPL_MFMA     0     /* f32 MFMA implicit-GEMM conv (default) */
+#define AIPT_DN_IMPL_VALU     1     /* plain per-thread direct conv (slow; on-GPU cross-check of the MFMA kernel) */
+
+/* blob: flat weight file, format in ai_path_tracer_denoiser_amd/arch.py (header + 28 x {W,b,gamma,beta,mean,var}). */
+int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);
+/* activations for frames of height x width (both multiples of 32: five 2x pools + skip concat). */
+int aipt_denoise_configure(aipt_ctx* ctx, int height, int width);
+int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
+/* forward: d_in10 float[10][H][W] -> d_out3 float[3][H][W] */
+int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags);
+int aipt_denoise_reset_hidden(aipt_ctx* ctx);
+/* checkpoint/resume of the recurrent state: level 0..4 = encoder1..5, 5 = bottleneck; d_buf float[C][H>>l][W>>l]. */
+int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst);
+int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src);
+
+/* ---- one frame: trace -> device G-buffer -> denoise (runCuda body, main.cpp:143-163) ------------------------ */
+/* Requires scene upload, aipt_frame_configure, weights.  Frames whose size is not a multiple of 32 are zero-padded
+ * at the bottom/right to the next multiple (the reference model cannot run them at all); d_out3 is
+ * float[3][height][width] (cropped). */
+int aipt_frame_configure(aipt_ctx* ctx, int width, int height);
+int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags, uint32_t dn_flags,
+               float* d_out3);
+/* the context-owned padded G-buffer float[10][Hp][Wp] written by aipt_frame (device pointer) and its padded size */
+int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
+/* per-stage GPU time of the last aipt_frame with timing enabled (ms; synchronous) */
+int aipt_frame_set_timing(aipt_ctx* ctx, int enabled);
+int aipt_frame_last_times(aipt_ctx* ctx, float* trace_ms, float* denoise_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIPTD_H */

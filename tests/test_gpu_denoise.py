@@ -1,0 +1,138 @@
+"""-m gpu: the HIP denoiser (through the C ABI) against the CPU oracle and the reference golden vectors.
+Tolerance: 1e-3 max abs per channel (BASELINE.json north_star), on fp32 activations."""
+import os
+
+import numpy as np
+import pytest
+
+from ai_path_tracer_denoiser_amd import api, arch, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _run_gpu(ctx, blob, frames, H, W, bn_batch, carry, impl=api.DN_IMPL_MFMA):
+    import torch
+    ctx.load_weights(blob)
+    ctx.denoise_configure(H, W)
+    ctx.denoise_set_impl(impl)
+    ctx.reset_hidden()
+    outs = []
+    for j, x in enumerate(frames):
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.empty(3, H, W, device="cuda")
+        ctx.denoise(xd, yd, bn_batch=bn_batch, carry=carry and j > 0)
+        ctx.sync()
+        outs.append(yd.cpu().numpy())
+    return outs
+
+
+@pytest.mark.parametrize("name", ["b_reset_64", "r_reset_64", "b_carry_64", "r_carry_64",
+                                  "b_carry_96x160", "r_reset_96x160"])
+def test_against_reference_goldens(ctx, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"denoise_{name}.npz"))
+    H, W, wseed, iseed, nfr, batch = [int(v) for v in g["meta"]]
+    frames = [synth.make_gbuffer(H, W, iseed, j) for j in range(nfr)]
+    outs = _run_gpu(ctx, synth.make_blob(wseed), frames, H, W, bool(batch), True)
+    for j in range(nfr):
+        ref = g["out"][j]
+        err = np.abs(outs[j] - ref).max()
+        assert err <= TOL * max(1.0, float(np.abs(ref).max()) / 8), (name, j, err)
+    import torch
+    for lvl, shp in enumerate(arch.hidden_shapes(H, W)):
+        h = torch.empty(*shp, device="cuda")
+        ctx.get_hidden(lvl, h)
+        ctx.sync()
+        hh = h.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(hh.reshape(shp[0], -1).mean(axis=1), g[f"h{lvl}_mean"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(hh.reshape(-1)[g[f"h{lvl}_idx"]], g[f"h{lvl}_samples"],
+                                   atol=TOL * max(1.0, float(np.abs(g[f"h{lvl}_samples"]).max())))
+
+
+@pytest.mark.parametrize("bn_batch", [True, False])
+@pytest.mark.parametrize("carry", [True, False])
+@pytest.mark.parametrize("impl", [api.DN_IMPL_MFMA, api.DN_IMPL_VALU])
+def test_against_oracle_small(ctx, bn_batch, carry, impl):
+    from oracle import DenoiseOracle
+    H, W = 64, 96
+    blob = synth.make_blob(11)
+    frames = [synth.make_gbuffer(H, W, 5, j) for j in range(2)]
+    outs = _run_gpu(ctx, blob, frames, H, W, bn_batch, carry, impl)
+    orc = DenoiseOracle(blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, bn_batch, carry and j > 0)
+        err = np.abs(outs[j] - ref).max()
+        assert err <= TOL, (bn_batch, carry, impl, j, err)
+
+
+def test_c1_size_256_against_oracle(ctx):
+    # BASELINE.json configs[0] frame size
+    from oracle import DenoiseOracle
+    H = W = 256
+    blob = synth.make_blob(565)
+    frames = [synth.make_gbuffer(H, W, 2, j) for j in range(2)]
+    outs = _run_gpu(ctx, blob, frames, H, W, True, True)
+    orc = DenoiseOracle(blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, True, j > 0)
+        assert np.abs(outs[j] - ref).max() <= TOL
+
+
+def test_hidden_checkpoint_resume(ctx):
+    import torch
+    H, W = 64, 64
+    blob = synth.make_blob(3)
+    frames = [synth.make_gbuffer(H, W, 9, j) for j in range(3)]
+    full = _run_gpu(ctx, blob, frames, H, W, True, True)
+    # run 2 frames, export the six hidden states, resume in a fresh context
+    _run_gpu(ctx, blob, frames[:2], H, W, True, True)
+    hs = []
+    for lvl, shp in enumerate(arch.hidden_shapes(H, W)):
+        h = torch.empty(*shp, device="cuda")
+        ctx.get_hidden(lvl, h)
+        hs.append(h)
+    ctx.sync()
+    c2 = api.Context(0)
+    c2.load_weights(blob)
+    c2.denoise_configure(H, W)
+    for lvl, h in enumerate(hs):
+        c2.set_hidden(lvl, h)
+    y = torch.empty(3, H, W, device="cuda")
+    c2.denoise(torch.from_numpy(frames[2]).cuda(), y, bn_batch=True, carry=True)
+    c2.sync()
+    assert np.abs(y.cpu().numpy() - full[2]).max() <= 1e-5
+    c2.close()
+
+
+def test_full_size_1280x736_properties(ctx):
+    """BASELINE.json configs[1] denoiser size: properties that need no oracle run."""
+    import torch
+    H, W = 736, 1280
+    blob = synth.make_blob(565)
+    frames = [synth.make_gbuffer(H, W, 1, j) for j in range(2)]
+    a = _run_gpu(ctx, blob, frames, H, W, True, True)
+    b = _run_gpu(ctx, blob, frames, H, W, True, True)
+    assert all(np.isfinite(o).all() for o in a)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])          # deterministic (no atomics in the stats)
+    r = _run_gpu(ctx, blob, frames, H, W, True, False)
+    assert np.array_equal(r[0], a[0]) and not np.array_equal(r[1], a[1])      # carry only matters from frame 1 on
+
+
+def test_rejects_bad_sizes_and_missing_weights():
+    c = api.Context(0)
+    with pytest.raises(api.AiptError):
+        c.denoise_configure(720, 1280)          # not a multiple of 32
+    import torch
+    c.denoise_configure(64, 64)
+    with pytest.raises(api.AiptError):
+        c.denoise(torch.zeros(10, 64, 64, device="cuda"), torch.zeros(3, 64, 64, device="cuda"))
+    with pytest.raises(api.AiptError):
+        c.load_weights(b"garbage-not-a-blob")
+    c.close()

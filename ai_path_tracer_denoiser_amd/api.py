@@ -106,6 +106,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise AiptError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950); this package has no CPU or PyTorch fallback")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).  Import it first so
+        # that libaiptd.so's DT_NEEDED libamdhip64.so.7 resolves to that already-loaded copy: two HIP runtimes in one
+        # process leave the second one without a GPU ("No HIP GPUs are available").
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, res, args in ABI:
             fn = getattr(L, name)          # AttributeError if a declared symbol is not exported

@@ -85,11 +85,29 @@ ABI = [
     ("aipt_denoise_reset_hidden", C.c_int, [_P]),
     ("aipt_denoise_get_hidden", C.c_int, [_P, C.c_int, _P]),
     ("aipt_denoise_set_hidden", C.c_int, [_P, C.c_int, _P]),
+    ("aipt_denoise_profile_begin", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("aipt_denoise_profile_end", C.c_int, [_P, _P, C.POINTER(C.c_int)]),
+    ("aipt_denoise_layer_info", C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
+     + [C.POINTER(C.c_double)]),
     ("aipt_frame_configure", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_frame", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, C.c_uint32, _P]),
     ("aipt_gbuffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aipt_frame_set_timing", C.c_int, [_P, C.c_int]),
     ("aipt_frame_last_times", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("aipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    ("aipt_scene_release", None, [_P]),
+    ("aipt_scene_set_resolution", C.c_int, [_P, C.c_int, C.c_int]),
+    ("aipt_scene_info", C.c_int, [_P] + [C.POINTER(C.c_int)] * 5),
+    ("aipt_scene_geoms", C.POINTER(Geom), [_P]),
+    ("aipt_scene_materials", C.POINTER(Material), [_P]),
+    ("aipt_scene_faces", C.POINTER(Face), [_P]),
+    ("aipt_scene_mesh_box", C.POINTER(AABB), [_P]),
+    ("aipt_scene_camera", C.c_int, [_P, C.POINTER(Camera)]),
+    ("aipt_scene_orbit_params", C.c_int, [_P] + [C.POINTER(C.c_float)] * 3),
+    ("aipt_scene_upload_host", C.c_int, [_P, _P]),
+    ("aipt_geom_build", None, [C.POINTER(Geom)]),
+    ("aipt_camera_orbit_params", None, [C.POINTER(Camera)] + [C.POINTER(C.c_float)] * 3),
+    ("aipt_camera_orbit", None, [C.POINTER(Camera), C.c_float, C.c_float, C.c_float]),
 ]
 
 _LIB = None
@@ -117,6 +135,70 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+class Scene:
+    """Host-side scene (reference class Scene, scene.h:13-44): parsed by the C++ front end of libaiptd.so."""
+
+    def __init__(self, path: str, res=None, depth=None):
+        L = lib()
+        h = _P()
+        err = C.create_string_buffer(512)
+        rc = L.aipt_scene_load(path.encode(), C.byref(h), err, 512)
+        if rc:
+            raise AiptError(f"aipt_scene_load({path}) failed ({rc}): {err.value.decode()}")
+        self._h = h
+        if res is not None:
+            rc = L.aipt_scene_set_resolution(h, int(res[0]), int(res[1]))
+            if rc:
+                raise AiptError(f"aipt_scene_set_resolution{tuple(res)} failed ({rc})")
+        n = [C.c_int() for _ in range(5)]
+        L.aipt_scene_info(h, *[C.byref(v) for v in n])
+        self.ngeoms, self.nmaterials, self.nfaces, self.iterations, self.depth = [v.value for v in n]
+        if depth is not None:
+            self.depth = depth
+        self.camera = Camera()
+        L.aipt_scene_camera(h, C.byref(self.camera))
+        z, p, t = C.c_float(), C.c_float(), C.c_float()
+        L.aipt_scene_orbit_params(h, C.byref(z), C.byref(p), C.byref(t))
+        self.zoom, self.phi, self.theta = z.value, p.value, t.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().aipt_scene_release(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def geoms(self):
+        p = lib().aipt_scene_geoms(self._h)
+        return [p[i] for i in range(self.ngeoms)]
+
+    @property
+    def materials(self):
+        p = lib().aipt_scene_materials(self._h)
+        return [p[i] for i in range(self.nmaterials)]
+
+    @property
+    def faces(self):
+        p = lib().aipt_scene_faces(self._h)
+        return [p[i] for i in range(self.nfaces)]
+
+    @property
+    def mesh_box(self):
+        return lib().aipt_scene_mesh_box(self._h).contents
+
+    def orbit(self, zoom=None, phi=None, theta=None) -> Camera:
+        """runCuda() camera rebuild (main.cpp:122-140); returns a Camera for this frame."""
+        cam = Camera.from_buffer_copy(bytes(self.camera))
+        lib().aipt_camera_orbit(C.byref(cam), self.zoom if zoom is None else zoom,
+                                self.phi if phi is None else phi, self.theta if theta is None else theta)
+        return cam
 
 
 class Context:
@@ -171,6 +253,12 @@ class Context:
         if width is not None:
             self._ck(lib().aipt_trace_configure(self._h, width, height))
 
+    def pathtrace_init_scene(self, scene: "Scene", width=None, height=None):
+        """pathtraceInit(Scene*) from a parsed Scene."""
+        self._ck(lib().aipt_scene_upload_host(self._h, scene._h))
+        if width is not None:
+            self._ck(lib().aipt_trace_configure(self._h, width, height))
+
     def pathtrace_free(self):
         self._ck(lib().aipt_scene_free(self._h))
 
@@ -216,6 +304,24 @@ class Context:
 
     def set_hidden(self, level: int, src):
         self._ck(lib().aipt_denoise_set_hidden(self._h, level, _P(src.data_ptr())))
+
+    def profile_begin(self, layer_mask: int, max_calls: int):
+        self._ck(lib().aipt_denoise_profile_begin(self._h, layer_mask, max_calls))
+
+    def profile_end(self):
+        """-> (summed ms per layer [28], number of recorded forwards)"""
+        ms = np.zeros(28, np.float64)
+        n = C.c_int()
+        self._ck(lib().aipt_denoise_profile_end(self._h, ms.ctypes.data, C.byref(n)))
+        return ms, n.value
+
+    def layer_info(self, layer: int):
+        name = C.create_string_buffer(64)
+        ci, co, h, w = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        fl = C.c_double()
+        self._ck(lib().aipt_denoise_layer_info(self._h, layer, name, 64, C.byref(ci), C.byref(co), C.byref(h),
+                                               C.byref(w), C.byref(fl)))
+        return dict(kernel=name.value.decode(), cin=ci.value, cout=co.value, h=h.value, w=w.value, flops=fl.value)
 
     # ------------------------------------------------------------------ frame (runCuda, main.cpp:143-163)
     def frame_configure(self, width: int, height: int):

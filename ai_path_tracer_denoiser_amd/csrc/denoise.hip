@@ -343,6 +343,11 @@ struct DenoiseState {
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA;
     std::vector<void*> allocs;
+    // per-layer HIP-event profiling (aipt_denoise_profile_*)
+    uint32_t prof_mask = 0;
+    int prof_max = 0, prof_calls = 0;
+    std::vector<hipEvent_t> prof_ev;     // [call][layer][2]
+    char kname[NLAYERS][40] = {};        // kernel that ran each layer in the last forward
 };
 
 static void build_table(int* cin, int* cout) {
@@ -374,6 +379,12 @@ static void free_weights(DenoiseState* s) {
     s->have_weights = false;
 }
 
+static void free_profile(DenoiseState* s) {
+    for (hipEvent_t e : s->prof_ev) if (e) hipEventDestroy(e);
+    s->prof_ev.clear();
+    s->prof_mask = 0; s->prof_max = 0; s->prof_calls = 0;
+}
+
 static void free_activations(DenoiseState* s) {
     for (void* p : s->allocs) hipFree(p);
     s->allocs.clear();
@@ -385,6 +396,7 @@ void denoise_destroy(aipt_ctx* ctx) {
     if (!ctx->dn) return;
     free_weights(ctx->dn);
     free_activations(ctx->dn);
+    free_profile(ctx->dn);
     delete ctx->dn;
     ctx->dn = nullptr;
 }
@@ -440,7 +452,11 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin) return fail(ctx, AIPT_E_STATE, "layer %d: %d input channels wired, %d expected", li, expect, L.cin);
     int nblk = 1;
+    const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max;
+    hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
+    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], ctx->stream));
     if (s->impl == AIPT_DN_IMPL_VALU) {
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_valu");
         g.partial = nullptr; g.nblk = 1;
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
@@ -453,6 +469,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         g.nblk = nblk;
         const dim3 grid((W + 16 * t.mbx - 1) / (16 * t.mbx), (H + 4 * t.rw - 1) / (4 * t.rw), L.NB / t.nbb);
         const int key = t.rw * 100 + t.mbx * 10 + t.nbb;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,%d>", t.rw, t.mbx, t.nbb);
         switch (key) {
             case 221: launch_mfma<2, 2, 1>(g, grid, ctx->stream); break;
             case 222: launch_mfma<2, 2, 2>(g, grid, ctx->stream); break;
@@ -464,6 +481,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             default: return fail(ctx, AIPT_E_STATE, "no conv instantiation for tile %d", key);
         }
     }
+    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], ctx->stream));
     hipLaunchKernelGGL(bn_finalize, dim3(L.cout), dim3(256), 0, ctx->stream, s->partial, nblk,
                        1.0 / ((double)H * (double)W), L.d_gamma, L.d_beta, batch ? nullptr : L.d_ab_running, dst.ab);
     AIPT_HIP(ctx, hipGetLastError());
@@ -659,7 +677,68 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
     }
     AIPT_HIP(ctx, hipGetLastError());
     s->hidden_valid = true;
+    if (s->prof_mask && s->prof_calls < s->prof_max) s->prof_calls++;
     return li == NLAYERS ? AIPT_OK : fail(ctx, AIPT_E_STATE, "aipt_denoise: ran %d layers", li);
+}
+
+int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (max_calls < 1 || max_calls > 4096) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_profile_begin: max_calls %d", max_calls);
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_profile(s);
+    s->prof_ev.resize((size_t)max_calls * NLAYERS * 2, nullptr);
+    for (int c = 0; c < max_calls; c++)
+        for (int l = 0; l < NLAYERS; l++)
+            if ((layer_mask >> l) & 1u)
+                for (int k = 0; k < 2; k++) AIPT_HIP(ctx, hipEventCreate(&s->prof_ev[((size_t)c * NLAYERS + l) * 2 + k]));
+    s->prof_mask = layer_mask & ((1u << NLAYERS) - 1u);
+    s->prof_max = max_calls;
+    s->prof_calls = 0;
+    return AIPT_OK;
+}
+
+int aipt_denoise_profile_end(aipt_ctx* ctx, double* sum_ms28, int* calls) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (sum_ms28) {
+        for (int l = 0; l < NLAYERS; l++) sum_ms28[l] = 0.0;
+        for (int c = 0; c < s->prof_calls; c++)
+            for (int l = 0; l < NLAYERS; l++)
+                if ((s->prof_mask >> l) & 1u) {
+                    float ms = 0;
+                    AIPT_HIP(ctx, hipEventElapsedTime(&ms, s->prof_ev[((size_t)c * NLAYERS + l) * 2],
+                                                      s->prof_ev[((size_t)c * NLAYERS + l) * 2 + 1]));
+                    sum_ms28[l] += ms;
+                }
+    }
+    if (calls) *calls = s->prof_calls;
+    std::vector<hipEvent_t> tmp;
+    tmp.swap(s->prof_ev);
+    for (hipEvent_t e : tmp) if (e) hipEventDestroy(e);
+    s->prof_mask = 0; s->prof_max = 0; s->prof_calls = 0;
+    return AIPT_OK;
+}
+
+int aipt_denoise_layer_info(aipt_ctx* ctx, int layer, char* kernel, size_t kernel_len, int* cin, int* cout,
+                            int* height, int* width, double* flops) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (layer < 0 || layer >= NLAYERS) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_layer_info: layer %d", layer);
+    if (!s->have_weights || !s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise_layer_info: weights + configure first");
+    int lvl;
+    if (layer < 15) lvl = layer / 3;                      // enc1..5
+    else if (layer < 18) lvl = 5;                         // bottleneck
+    else lvl = 4 - (layer - 18) / 2;                      // dec5..dec1 run at levels 4..0
+    const int h = s->H >> lvl, w = s->W >> lvl;
+    if (kernel && kernel_len) { strncpy(kernel, s->kname[layer], kernel_len - 1); kernel[kernel_len - 1] = 0; }
+    if (cin) *cin = s->L[layer].cin;
+    if (cout) *cout = s->L[layer].cout;
+    if (height) *height = h;
+    if (width) *width = w;
+    if (flops) *flops = 2.0 * 9.0 * s->L[layer].cin * s->L[layer].cout * (double)h * (double)w;
+    return AIPT_OK;
 }
 
 int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst) {

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- denoised frames/s @1280x720, 1 spp, depth 8 (BASELINE.json metric) on N MI355X GPUs of one node.
+
+Workload (BASELINE.json configs[1]): Cornell box 1280x720, 1 spp, depth 8, orbit pan, recurrent hidden state carried;
+BatchNorm in batch-statistics mode (what the reference's shipped TorchScript computes) -- the most expensive
+of the four denoiser modes.  A "step" is one frame: path trace -> device G-buffer -> denoise (aipt_frame).  Inputs
+(scene, weights) are resident in HBM before the timed region; nothing crosses PCIe per frame.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU; frames are sharded, scene + weights broadcast once
+     from rank 0 over RCCL; no per-frame collective -> "scaling": "weak")
+
+Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the dominant kernel (HIP events on the launch stream
+inside the timed region), "cpu_baseline" (the CPU oracle timed on the host cores, N=1 only), "frame" (ms split and the
+whole-frame HBM fraction).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MI355X_HBM_BPS = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MI355X_FP32_MFMA_TFLOPS = 157.3  # f32-input MFMA dense peak = fp32 vector peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
+    ap.add_argument("--bn", choices=["batch", "running"], default="batch")
+    ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-events", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ai_path_tracer_denoiser_amd import api, arch, synth
+    from ai_path_tracer_denoiser_amd import dist as adist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    W, H, depth = args.width, args.height, args.depth
+    stream = torch.cuda.Stream(device=dev)
+    ctx = api.Context(local_rank, stream.cuda_stream)
+
+    # ---- rank 0 parses the scene and makes the weights; one broadcast each (RCCL over xGMI)
+    scene_blob = weight_blob = None
+    cam_bytes = None
+    if rank == 0:
+        sc = api.Scene(args.scene, res=(W, H), depth=depth)
+        scene_blob = adist.pack_scene(sc.geoms, sc.materials, sc.faces, sc.mesh_box if sc.nfaces else None)
+        weight_blob = synth.make_blob(565)
+        cam_bytes = bytes(sc.camera) + np.array([sc.zoom, sc.phi, sc.theta], np.float32).tobytes()
+    scene_blob = adist.broadcast_bytes(scene_blob, 0, dev)
+    weight_blob = adist.broadcast_bytes(weight_blob, 0, dev)
+    cam_bytes = adist.broadcast_bytes(cam_bytes, 0, dev)
+    geoms, mats, faces, box = adist.unpack_scene(scene_blob)
+    cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
+    zoom, phi0, theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
+
+    ctx.pathtrace_init(geoms, mats, faces, box if faces else None)
+    ctx.load_weights(weight_blob)
+    ctx.frame_configure(W, H)
+    out = torch.empty(3, H, W, device=dev)
+    bn_batch = args.bn == "batch"
+    carry = args.hidden == "carry"
+
+    per_rank = args.warmup + args.steps
+    frames = list(adist.frame_shard(rank, world, per_rank))
+
+    def camera_for(g):
+        cam = api.Camera.from_buffer_copy(bytes(cam0))
+        api.lib().aipt_camera_orbit(cam, zoom, adist.pan_phi(phi0, g), theta)
+        return cam
+
+    cams = [camera_for(g) for g in frames]
+
+    def run_frame(k):
+        ctx.frame(cams[k], 1, depth, out, bn_batch=bn_batch, carry=carry and k > 0)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- warmup; on the first warmup frames time every conv layer to find the dominant kernel
+    prof_layers = None
+    if args.warmup > 0 and not args.no_roofline_events:
+        nprof = min(3, args.warmup)
+        ctx.profile_begin((1 << 28) - 1, nprof)
+    for k in range(args.warmup):
+        run_frame(k)
+    layer_tbl = None
+    if args.warmup > 0 and not args.no_roofline_events:
+        ms28, ncalls = ctx.profile_end()
+        layer_tbl = [ctx.layer_info(l) for l in range(28)]
+        by_kernel = {}
+        for l, info in enumerate(layer_tbl):
+            by_kernel.setdefault(info["kernel"], []).append(l)
+        dominant = max(by_kernel, key=lambda kn: sum(ms28[l] for l in by_kernel[kn]))
+        prof_layers = by_kernel[dominant]
+    barrier()
+
+    # ---- timed region: exactly K frames
+    if prof_layers:
+        ctx.profile_begin(sum(1 << l for l in prof_layers), args.steps)
+    ctx.frame_set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup, per_rank):
+        run_frame(k)
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    trace_ms, denoise_ms = ctx.frame_last_times()
+    roof = None
+    if prof_layers:
+        ms28, ncalls = ctx.profile_end()
+        launches = ncalls * len(prof_layers)
+        tot_ms = float(sum(ms28[l] for l in prof_layers))
+        flops_per_frame = sum(layer_tbl[l]["flops"] for l in prof_layers)
+        avg_ms = tot_ms / max(1, launches)
+        achieved = flops_per_frame * ncalls / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MI355X_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MI355X_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "kernel": dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
+                "flops_per_launch": flops_per_frame / len(prof_layers),
+                "layers": [arch.layer_table()[l][0] for l in prof_layers]}
+
+    fps = world * args.steps / elapsed
+    n_live = ctx.live_counts(depth)
+    P = W * H
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    trace_bytes = float(sum(int(n) for n in n_live[:depth]) * 160 + P * 64)        # SURVEY 8d byte model
+    dn_bytes = float(arch.activation_bytes(Hp, Wp))
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # ---- CPU baseline: the oracle (a port, test infrastructure) on the host cores, one frame of the same workload
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        osc = oracle.OracleScene.parse(args.scene, res=(W, H), depth=depth)
+        osc.set_orbit(osc.zoom, adist.pan_phi(osc.phi, 0), osc.theta)
+        c0 = time.perf_counter()
+        g_ref, _, _ = osc.pathtrace(pad_rows_to=Hp, want_mat0=False)
+        c1 = time.perf_counter()
+        orc = oracle.DenoiseOracle(weight_blob, Hp, Wp)
+        gp = np.zeros((10, Hp, Wp), np.float32)
+        gp[:, :, :W] = g_ref
+        orc.forward(gp, bn_batch, False)
+        c2 = time.perf_counter()
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+        cpu = {"value": round(1.0 / (c2 - c0), 4), "unit": "frames/s", "cores": cores, "kind": "port",
+               "sample": f"1 frame of the same workload ({W}x{H} depth {depth}): oracle trace {c1 - c0:.2f} s + "
+                         f"oracle denoise {c2 - c1:.2f} s (C/OpenMP restatement, fp32)"}
+
+    if rank == 0:
+        line = {
+            "metric": "denoised frames/sec @1280x720 1spp depth8", "value": round(fps, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cornell box (7 primitives, no mesh) {W}x{H}, 1spp, depth {depth}, orbit pan, "
+                                   f"BN {args.bn}-stats, hidden {args.hidden}",
+                       "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
+                       "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "frame": {"ms_trace_last": round(trace_ms, 4), "ms_denoise_last": round(denoise_ms, 4),
+                      "algorithmic_bytes": trace_bytes + dn_bytes, "denoise_gflop": arch.conv_flops(Hp, Wp) / 1e9,
+                      "hbm_frac_of_8TBps": round((trace_bytes + dn_bytes) / (ms_per_step * 1e-3) / MI355X_HBM_BPS, 5),
+                      "n_live": [int(v) for v in n_live]},
+        }
+        print(json.dumps(line))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

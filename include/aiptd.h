@@ -13,7 +13,8 @@
  *   torch::jit::load(MODEL_PATH)            src/main.cpp:107       aipt_denoise_load_weights
  *   module.forward({[1,10,W,H]}) -> [1,3,W,H] src/main.cpp:104-111 aipt_denoise
  *   runCuda() per-frame body                src/main.cpp:143-163   aipt_frame
- *   Scene::Scene(filename)                  src/scene.cpp:11-42    aipt_scene_load (host-side front end)
+ *   Scene::Scene(filename)                  src/scene.cpp:11-320   aipt_scene_load (host-side front end)
+ *   camera orbit rebuild in runCuda()       src/main.cpp:122-140   aipt_camera_orbit
  *
  * The POD structs below have the byte layout of the reference's sceneStructs.h types (glm::vec3 = 3 floats,
  * glm::mat4 = 16 floats column-major), so a reference-side caller can pass scene->geoms.data() etc. directly
@@ -160,6 +161,14 @@ int aipt_denoise_reset_hidden(aipt_ctx* ctx);
 int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst);
 int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src);
 
+/* per-conv-layer HIP-event timing on the context stream (bench.py's roofline leg).  layer_mask: bit l = time layer l
+ * (0..27, network order); up to max_calls forward passes are recorded; _end synchronises and returns the summed ms. */
+int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls);
+int aipt_denoise_profile_end(aipt_ctx* ctx, double* sum_ms28, int* calls);
+/* kernel instantiation that ran `layer` in the last forward, its shape and algorithmic FLOPs (2*9*cin*cout*h*w) */
+int aipt_denoise_layer_info(aipt_ctx* ctx, int layer, char* kernel, size_t kernel_len, int* cin, int* cout,
+                            int* height, int* width, double* flops);
+
 /* ---- one frame: trace -> device G-buffer -> denoise (runCuda body, main.cpp:143-163) ------------------------ */
 /* Requires scene upload, aipt_frame_configure, weights.  Frames whose size is not a multiple of 32 are zero-padded
  * at the bottom/right to the next multiple (the reference model cannot run them at all); d_out3 is
@@ -172,6 +181,28 @@ int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
 /* per-stage GPU time of the last aipt_frame with timing enabled (ms; synchronous) */
 int aipt_frame_set_timing(aipt_ctx* ctx, int enabled);
 int aipt_frame_last_times(aipt_ctx* ctx, float* trace_ms, float* denoise_ms);
+
+/* ---- host-side scene front end (scene.cpp:11-320, utilities.cpp:45-52, main.cpp:66-78,122-140) -------------- */
+typedef struct aipt_scene aipt_scene;
+/* Parses the reference's scene grammar (MATERIAL / OBJECT / CAMERA / MESH blocks), builds the three matrices of every
+ * primitive, loads + transforms the OBJ mesh and its bounding box, and sets the first-frame orbit camera.
+ * err (optional) receives the message on failure. */
+int  aipt_scene_load(const char* path, aipt_scene** out, char* err, size_t errlen);
+void aipt_scene_release(aipt_scene* scene);
+int  aipt_scene_set_resolution(aipt_scene* scene, int width, int height);   /* override RES; recomputes fov/pixelLength */
+int  aipt_scene_info(const aipt_scene* scene, int* ngeoms, int* nmaterials, int* nfaces, int* iterations, int* depth);
+const aipt_geom*     aipt_scene_geoms(const aipt_scene* scene);
+const aipt_material* aipt_scene_materials(const aipt_scene* scene);
+const aipt_face*     aipt_scene_faces(const aipt_scene* scene);
+const aipt_aabb*     aipt_scene_mesh_box(const aipt_scene* scene);
+int  aipt_scene_camera(const aipt_scene* scene, aipt_camera* cam_out);        /* first-frame camera */
+int  aipt_scene_orbit_params(const aipt_scene* scene, float* zoom, float* phi, float* theta);   /* as main() derives them */
+int  aipt_scene_upload_host(aipt_ctx* ctx, const aipt_scene* scene);          /* aipt_scene_upload of the parsed arrays */
+/* transform / inverseTransform / invTranspose of one primitive from its translation, rotation (degrees), scale */
+void aipt_geom_build(aipt_geom* geom);
+/* orbit camera: parameters from a loaded camera (main.cpp:66-78) and the per-frame rebuild (main.cpp:122-140) */
+void aipt_camera_orbit_params(const aipt_camera* cam, float* zoom, float* phi, float* theta);
+void aipt_camera_orbit(aipt_camera* cam, float zoom, float phi, float theta);
 
 #ifdef __cplusplus
 }

@@ -70,31 +70,73 @@ __device__ __forceinline__ float load_src(const ConvSrc& s, int ch, int y, int x
 // -------------------------------------------------------------------------------------------------- MFMA conv
 // Block = 256 threads = 4 waves.  Tile = (4*RW) rows x (16*MBX) cols of output pixels x (16*NBB) output channels
 // (blockIdx.z selects the channel group).  Wave w owns rows [w*RW, w*RW+RW) of the tile.
+//
+// Software pipeline over 8-channel chunks, LDS double-buffered, ONE barrier per chunk:
+//     issue global loads of chunk c+1 (halo tile + weight slab) into registers
+//     9 taps x 2 k-steps of MFMA on chunk c from LDS[cur]
+//     transform (BN affine + LReLU) and write chunk c+1 into LDS[cur^1];  barrier
+// so HBM/L2 latency hides under the MFMAs of the same workgroup.  The (channel, row, col) -> address decomposition of a
+// thread's staging elements does not depend on the chunk and is done once before the loop.
 template <int RW, int MBX, int NBB>
 struct ConvCfg {
     static constexpr int TH = 4 * RW, TW = 16 * MBX;
     static constexpr int RS = TW + 2;                               // LDS row stride of the halo tile
-    static constexpr int CS0 = (TH + 2) * RS;
-    static constexpr int CS = CS0 + ((16 - (CS0 % 32)) + 32) % 32;  // channel stride == 16 (mod 32): k and k+1 hit disjoint banks
+    static constexpr int PL = (TH + 2) * RS;                        // halo pixels per channel
+    static constexpr int CS = PL + ((16 - (PL % 32)) + 32) % 32;    // channel stride == 16 (mod 32): k and k+1 hit disjoint banks
     static constexpr int NPB0 = 16 * NBB;
     static constexpr int NPB = NPB0 + ((16 - (NPB0 % 32)) + 32) % 32;
     static constexpr int A_FLOATS = KC * CS;
     static constexpr int B_FLOATS = 9 * KC * NPB;
+    static constexpr int STAGE = A_FLOATS + B_FLOATS;               // one pipeline stage
+    static constexpr int NE = (KC * PL + 255) / 256;                // halo elements per thread
+    static constexpr int NW = (9 * KC * NBB * 4 + 255) / 256;       // weight float4 per thread
+    static constexpr int MAXC = 208;                                // >= max concat channels (202), multiple of KC
 };
 
 template <int RW, int MBX, int NBB>
-__global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs g) {
+__global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >= 4) ? 3 : 4) void conv3x3_mfma(const ConvArgs g) {
     using Cfg = ConvCfg<RW, MBX, NBB>;
-    constexpr int TH = Cfg::TH, TW = Cfg::TW, RS = Cfg::RS, CS = Cfg::CS, NPB = Cfg::NPB;
-    __shared__ __attribute__((aligned(16))) float smem[Cfg::A_FLOATS + Cfg::B_FLOATS];
-    float* As = smem;
-    float* Bs = smem + Cfg::A_FLOATS;
+    constexpr int TH = Cfg::TH, TW = Cfg::TW, RS = Cfg::RS, PL = Cfg::PL, CS = Cfg::CS, NPB = Cfg::NPB;
+    constexpr int NE = Cfg::NE, NW = Cfg::NW;
+    __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE + 2 * Cfg::MAXC];
+    float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::STAGE);   // per concat channel (a, b)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
     const int n0 = blockIdx.z * NBB * 16;      // first output channel of this block
     const int H = g.H, W = g.W;
     const int lk = lane >> 4, li = lane & 15;
+    const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    const int up = g.a.up;                     // both sources share the resampling mode (host checks)
+    const int sw = up ? (W >> 1) : W;
+    const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+
+    for (int c = tid; c < ctot; c += 256) {
+        float2 t = make_float2(1.0f, 0.0f);
+        if (c < aC) { if (g.a.ab) t = g.a.ab[c]; }
+        else if (g.b.ab) t = g.b.ab[c - aC];
+        abs_tab[c] = t;
+    }
+
+    // ---- chunk-invariant part of this thread's staging elements.  Loads are issued UNCONDITIONALLY from clamped
+    // addresses and masked afterwards: a branch around a load makes hipcc wait vmcnt(0) per element.
+    static_assert(CS > PL, "the padding floats of channel 0 serve as the dump slot of out-of-range staging elements");
+    int e_goff[NE], e_lds[NE], e_c[NE];
+    unsigned in_mask = 0;
+#pragma unroll
+    for (int j = 0; j < NE; j++) {
+        const int e = tid + j * 256;
+        const int c = e / PL;
+        const int rem = e - c * PL;
+        const int yy = rem / RS, xx = rem - yy * RS;
+        const int y = ty0 + yy - 1, x = tx0 + xx - 1;
+        const bool valid = e < KC * PL;
+        const bool in = valid && y >= 0 && y < H && x >= 0 && x < W;
+        e_c[j] = valid ? c : 0;
+        e_lds[j] = valid ? c * CS + yy * RS + xx : PL;
+        e_goff[j] = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
+        in_mask |= in ? (1u << j) : 0u;
+    }
 
     f32x4 acc[RW][MBX][NBB];
 #pragma unroll
@@ -104,32 +146,52 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs g) {
 #pragma unroll
             for (int n = 0; n < NBB; n++) acc[r][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ctot = g.a.C + g.b.C;
+    float pa[NE];
+    f32x4 pw[NW];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            int cg = chunk * KC + e_c[j];
+            cg = cg < ctot ? cg : ctot - 1;
+            const float* base = cg < aC ? g.a.p + (size_t)cg * plane : g.b.p + (size_t)(cg - aC) * plane;
+            pa[j] = base[e_goff[j]];
+        }
+        const float* wsrc = g.w + (size_t)chunk * 9 * KC * g.NP + n0;
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            int e = tid + j * 256;
+            e = e < 9 * KC * NBB * 4 ? e : 9 * KC * NBB * 4 - 1;
+            const int row = e / (NBB * 4), q = e - row * (NBB * 4);
+            pw[j] = *reinterpret_cast<const f32x4*>(wsrc + (size_t)row * g.NP + q * 4);
+        }
+    };
+    auto stash = [&](int chunk, float* As, float* Bs) {
+#pragma unroll
+        for (int j = 0; j < NE; j++) {
+            const int cg = chunk * KC + e_c[j];
+            const bool ok = ((in_mask >> j) & 1u) && cg < ctot;
+            const float2 t = abs_tab[cg < ctot ? cg : ctot - 1];
+            const float v = lrelu(fmaf(t.x, pa[j], t.y), cg < aC ? g.a.slope : g.b.slope);
+            As[e_lds[j]] = ok ? v : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NW; j++) {
+            const int e = tid + j * 256;
+            const int row = e / (NBB * 4), q = e - row * (NBB * 4);
+            if (e < 9 * KC * NBB * 4) *reinterpret_cast<f32x4*>(Bs + row * NPB + q * 4) = pw[j];
+        }
+    };
+
+    fetch(0);
+    __syncthreads();                           // abs_tab visible
+    stash(0, smem, smem + Cfg::A_FLOATS);
+    __syncthreads();
+
     for (int chunk = 0; chunk < g.nchunks; chunk++) {
-        __syncthreads();
-        // ---- stage the halo tile of KC input channels, applying the producer's pending BN affine + LReLU
-        for (int e = tid; e < KC * (TH + 2) * RS; e += 256) {
-            const int c = e / ((TH + 2) * RS);
-            const int rem = e - c * ((TH + 2) * RS);
-            const int yy = rem / RS, xx = rem - yy * RS;
-            const int y = ty0 + yy - 1, x = tx0 + xx - 1;
-            const int cg = chunk * KC + c;
-            float v = 0.0f;
-            if (cg < ctot && y >= 0 && y < H && x >= 0 && x < W)
-                v = cg < g.a.C ? load_src(g.a, cg, y, x, H, W) : load_src(g.b, cg - g.a.C, y, x, H, W);
-            As[c * CS + yy * RS + xx] = v;
-        }
-        // ---- stage the weight slab [9][KC][NBB*16] of this chunk / channel group
-        {
-            const float* wsrc = g.w + (size_t)chunk * 9 * KC * g.NP + n0;
-            constexpr int ROWF4 = NBB * 4;                 // float4 per (tap,kc) row
-            for (int e = tid; e < 9 * KC * ROWF4; e += 256) {
-                const int row = e / ROWF4, q = e - row * ROWF4;
-                const float4 v = *reinterpret_cast<const float4*>(wsrc + (size_t)row * g.NP + q * 4);
-                *reinterpret_cast<float4*>(Bs + row * NPB + q * 4) = v;
-            }
-        }
-        __syncthreads();
+        const float* As = smem + (chunk & 1) * Cfg::STAGE;
+        const float* Bs = As + Cfg::A_FLOATS;
+        const bool more = chunk + 1 < g.nchunks;
+        if (more) fetch(chunk + 1);
         // ---- 9 taps x 2 k-steps of v_mfma_f32_16x16x4_f32
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
@@ -152,6 +214,11 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs g) {
                 }
             }
         }
+        if (more) {
+            float* An = smem + ((chunk + 1) & 1) * Cfg::STAGE;
+            stash(chunk + 1, An, An + Cfg::A_FLOATS);
+        }
+        __syncthreads();
     }
 
     // ---- epilogue: bias (+LReLU), store raw output, per-channel sum / sum-of-squares partials
@@ -194,8 +261,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma(const ConvArgs g) {
         }
     }
     if (g.partial) {
-        __syncthreads();                        // everyone is done with As/Bs
-        float2* red = reinterpret_cast<float2*>(smem);     // [4 waves][NBB*16]
+        float2* red = reinterpret_cast<float2*>(smem);     // [4 waves][NBB*16]; the last loop barrier already passed
 #pragma unroll
         for (int n = 0; n < NBB; n++) {
             float a = s1[n], b = s2[n];
@@ -449,6 +515,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
     g.nchunks = (g.a.C + g.b.C + KC - 1) / KC;
     g.out = dst.p; g.out_lrelu = out_lrelu;
+    if (B && use_b && upA != upB) return fail(ctx, AIPT_E_STATE, "layer %d: concat sources must share the resampling mode", li);
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin) return fail(ctx, AIPT_E_STATE, "layer %d: %d input channels wired, %d expected", li, expect, L.cin);
     int nblk = 1;

@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
     args = ap.parse_args()
 
     import numpy as np
@@ -120,6 +121,13 @@ def main():
         for l, info in enumerate(layer_tbl):
             by_kernel.setdefault(info["kernel"], []).append(l)
         dominant = max(by_kernel, key=lambda kn: sum(ms28[l] for l in by_kernel[kn]))
+        if args.layers and rank == 0:
+            names = [t[0] for t in arch.layer_table()]
+            for l, info in enumerate(layer_tbl):
+                ms = ms28[l] / max(1, ncalls)
+                print(f"{names[l]:9s} {info['cin']:3d}->{info['cout']:3d} {info['h']:4d}x{info['w']:<4d} {info['kernel']:22s} "
+                      f"{ms * 1e3:8.1f} us {info['flops'] / ms / 1e9 if ms > 0 else 0:7.1f} TF", file=sys.stderr)
+            print(f"conv total {sum(ms28) / max(1, ncalls):.3f} ms", file=sys.stderr)
         prof_layers = by_kernel[dominant]
     barrier()
 

@@ -281,6 +281,234 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
     }
 }
 
+// -------------------------------------------------------------------------------------------------- split-fp16 MFMA conv
+// Same implicit GEMM, but on v_mfma_f32_32x32x16_f16 with every fp32 operand split as x = hi + lo * 2^-11
+// (hi = fp16(x), lo = fp16((x - hi) * 2^11)); three MFMAs per product keep hi*hi, hi*lo and lo*hi, accumulated in fp32
+// (the dropped lo*lo term is 2^-22 relative).  Measured accuracy equals the fp32 FMA chain, at 16/3 of its
+// MFMA rate.  M = 32 consecutive pixels of a row, N = 32 output channels, K = 16 input channels of one tap.
+// Block = 4 waves, tile = (4*RW) rows x 32 cols x 32 output channels (blockIdx.z = channel group of 32).
+// LDS holds activations channel-last as [pixel][16 hi halfs | pad] and [pixel][16 lo halfs | pad] (48-byte pixel stride:
+// ds_read_b128 / ds_write_b64 conflict-free) and the pre-split weight slab [tap][cout][16 | pad] hi and lo.
+// Single LDS stage + register prefetch: the next chunk's global loads are in flight during the MFMAs.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KH = 16;             // input channels per chunk of the fp16 kernel
+constexpr int PXB = 48;            // bytes per pixel / per weight row in LDS (16 halfs + 8 halfs padding)
+
+struct ConvArgsH {
+    ConvSrc a, b;
+    int H, W;
+    const _Float16* whi;   // [nchunks][9][coutp][16]
+    const _Float16* wlo;
+    const float* bias;     // [coutp]
+    int cout, coutp, nchunks;
+    float* out;
+    int out_lrelu;
+    float2* partial;
+    int nblk;
+};
+
+template <int RW>
+struct ConvCfgH {
+    static constexpr int TH = 4 * RW, TW = 32;
+    static constexpr int RS = TW + 2;
+    static constexpr int PL = (TH + 2) * RS;
+    static constexpr int A_BYTES = PL * PXB;                 // one of hi / lo
+    static constexpr int B_BYTES = 9 * 32 * PXB;             // one of hi / lo
+    static constexpr int NU = (4 * PL + 255) / 256;          // (pixel, channel-quad) staging units per thread
+    static constexpr int NWP = (9 * 32 * 2 * 2 + 255) / 256; // 16-byte weight pieces per thread (hi and lo)
+    static constexpr int MAXC = 208;
+};
+
+template <int RW>
+__global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
+    using Cfg = ConvCfgH<RW>;
+    constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU, NWP = Cfg::NWP;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES + 8 * Cfg::MAXC];
+    unsigned char* Ahi = smem;
+    unsigned char* Alo = smem + Cfg::A_BYTES;
+    unsigned char* Bhi = smem + 2 * Cfg::A_BYTES;
+    unsigned char* Blo = Bhi + Cfg::B_BYTES;
+    float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * TH;
+    const int n0 = blockIdx.z * 32;
+    const int H = g.H, W = g.W;
+    const int li = lane & 31, lg = lane >> 5;
+    const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    const int up = g.a.up;
+    const int sw = up ? (W >> 1) : W;
+    const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+
+    for (int c = tid; c < ctot; c += 256) {
+        float2 t = make_float2(1.0f, 0.0f);
+        if (c < aC) { if (g.a.ab) t = g.a.ab[c]; }
+        else if (g.b.ab) t = g.b.ab[c - aC];
+        abs_tab[c] = t;
+    }
+
+    // chunk-invariant staging units: unit u -> (channel quad q, halo pixel)
+    int u_goff[NU], u_lds[NU], u_q[NU];
+    unsigned in_mask = 0;
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+        const int u = tid + j * 256;
+        const int q = u / PL;
+        const int pix = u - q * PL;
+        const int yy = pix / RS, xx = pix - yy * RS;
+        const int y = ty0 + yy - 1, x = tx0 + xx - 1;
+        const bool valid = u < 4 * PL;
+        const bool in = valid && y >= 0 && y < H && x >= 0 && x < W;
+        u_q[j] = valid ? q : 0;
+        u_lds[j] = valid ? pix * PXB + q * 8 : 32;            // bytes 32..47 of pixel 0 are padding: dump slot
+        u_goff[j] = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
+        in_mask |= in ? (1u << j) : 0u;
+    }
+
+    f32x16 acc0[RW], acc1[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) { acc0[r][q] = 0.f; acc1[r][q] = 0.f; }
+
+    float pa[NU][4];
+    u32x4 pw[NWP];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                int cg = chunk * KH + u_q[j] * 4 + t;
+                cg = cg < ctot ? cg : ctot - 1;
+                const float* base = cg < aC ? g.a.p + (size_t)cg * plane : g.b.p + (size_t)(cg - aC) * plane;
+                pa[j][t] = base[u_goff[j]];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; j++) {
+            int p = tid + j * 256;
+            p = p < 9 * 32 * 4 ? p : 9 * 32 * 4 - 1;
+            const int lo = p >= 9 * 32 * 2;                    // second half of the pieces = lo slab
+            const int pp = lo ? p - 9 * 32 * 2 : p;
+            const int tap = pp >> 6, rr = pp & 63, jj = rr >> 1, hh = rr & 1;
+            const _Float16* src = (lo ? g.wlo : g.whi) + (((size_t)chunk * 9 + tap) * g.coutp + n0 + jj) * KH + hh * 8;
+            pw[j] = *reinterpret_cast<const u32x4*>(src);
+        }
+    };
+    auto stash = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            f16x4 hv, lv;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int cg = chunk * KH + u_q[j] * 4 + t;
+                const bool ok = ((in_mask >> j) & 1u) && cg < ctot;
+                const float2 ab = abs_tab[cg < ctot ? cg : ctot - 1];
+                float v = lrelu(fmaf(ab.x, pa[j][t], ab.y), cg < aC ? g.a.slope : g.b.slope);
+                v = ok ? v : 0.0f;
+                const _Float16 h = (_Float16)v;
+                hv[t] = h;
+                lv[t] = (_Float16)((v - (float)h) * 2048.0f);
+            }
+            *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = hv;
+            *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = lv;
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; j++) {
+            const int p = tid + j * 256;
+            if (p < 9 * 32 * 4) {
+                const int lo = p >= 9 * 32 * 2;
+                const int pp = lo ? p - 9 * 32 * 2 : p;
+                const int row = pp >> 1, hh = pp & 1;         // row = tap*32 + jj
+                *reinterpret_cast<u32x4*>((lo ? Blo : Bhi) + row * PXB + hh * 16) = pw[j];
+            }
+        }
+    };
+
+    fetch(0);
+    __syncthreads();                                           // abs_tab visible
+    for (int chunk = 0; chunk < g.nchunks; chunk++) {
+        stash(chunk);
+        __syncthreads();
+        if (chunk + 1 < g.nchunks) fetch(chunk + 1);
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            f16x8 fah[RW + 2], fal[RW + 2];
+#pragma unroll
+            for (int hr = 0; hr < RW + 2; hr++) {
+                const int off = ((wave * RW + hr) * RS + li + kx) * PXB + lg * 16;
+                fah[hr] = *reinterpret_cast<const f16x8*>(Ahi + off);
+                fal[hr] = *reinterpret_cast<const f16x8*>(Alo + off);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                const int boff = ((ky * 3 + kx) * 32 + li) * PXB + lg * 16;
+                const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bhi + boff);
+                const f16x8 fbl = *reinterpret_cast<const f16x8*>(Blo + boff);
+#pragma unroll
+                for (int r = 0; r < RW; r++) {
+                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
+                    acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
+                    acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc1[r], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  D fragment (32x32): register q of lane l = pixel (q&3) + 8*(q>>2) + 4*(l>>5), channel l&31.
+    const int j = n0 + li;
+    const bool jok = j < g.cout;
+    const float bj = g.bias[j < g.coutp ? j : 0];
+    float s1 = 0.f, s2 = 0.f;
+    const bool vec_ok = (W & 3) == 0;
+#pragma unroll
+    for (int r = 0; r < RW; r++) {
+        const int y = ty0 + wave * RW + r;
+#pragma unroll
+        for (int qq = 0; qq < 4; qq++) {
+            const int xb = tx0 + 8 * qq + 4 * lg;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float t = (acc0[r][qq * 4 + q] + acc1[r][qq * 4 + q] * (1.0f / 2048.0f)) + bj;
+                if (g.out_lrelu) t = lrelu(t, SLOPE);
+                v[q] = t;
+            }
+            if (jok && y < H) {
+                float* o = g.out + ((size_t)j * H + y) * W + xb;
+                if (vec_ok && xb + 3 < W) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { s1 += v[q]; s2 += v[q] * v[q]; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (xb + q < W) { o[q] = v[q]; s1 += v[q]; s2 += v[q] * v[q]; }
+                }
+            }
+        }
+    }
+    if (g.partial) {
+        float2* red = reinterpret_cast<float2*>(smem);         // [4 waves][32]; the last loop barrier already passed
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        if (lg == 0) red[wave * 32 + li] = make_float2(s1, s2);
+        __syncthreads();
+        if (tid < 32) {
+            const int jj = n0 + tid;
+            if (jj < g.cout) {
+                float2 t = red[tid];
+                for (int w = 1; w < 4; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
+                g.partial[(size_t)jj * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- VALU conv
 // One thread per output element; reads its 9*cin taps straight from HBM.  Only for on-GPU cross-checks.
 __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
@@ -388,6 +616,10 @@ struct LayerW {
     int cin = 0, cout = 0, NB = 0, NP = 0, nchunks = 0;
     float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
     float2* d_ab_running = nullptr;
+    // split-fp16 copy of the weights for conv3x3_f16x3: [nchunks16][9][coutp32][16] hi and lo*2^11
+    int coutp32 = 0, nchunks16 = 0;
+    _Float16 *d_whi = nullptr, *d_wlo = nullptr;
+    float* d_bias32 = nullptr;
 };
 
 struct Tensor {
@@ -439,7 +671,7 @@ static void build_table(int* cin, int* cout) {
 static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
-        hipFree(l.d_ab_running);
+        hipFree(l.d_ab_running); hipFree(l.d_whi); hipFree(l.d_wlo); hipFree(l.d_bias32);
         l = LayerW();
     }
     s->have_weights = false;
@@ -528,6 +760,21 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, s->partial);
+    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= 200000 && H % 8 == 0) {
+        // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
+        ConvArgsH gh;
+        gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
+        gh.whi = L.d_whi; gh.wlo = L.d_wlo; gh.bias = L.d_bias32;
+        gh.cout = L.cout; gh.coutp = L.coutp32;
+        gh.nchunks = (g.a.C + g.b.C + KH - 1) / KH;
+        gh.out = dst.p; gh.out_lrelu = out_lrelu;
+        const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
+        nblk = grid.x * grid.y;
+        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        gh.partial = batch ? s->partial : nullptr;
+        gh.nblk = nblk;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<2>");
+        hipLaunchKernelGGL((conv3x3_f16x3<2>), grid, dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
         nblk = conv_nblk(t, H, W);
@@ -610,6 +857,29 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             const double sc = (double)gamma[j] / sqrt((double)var[j] + (double)BN_EPS);
             abr[j] = make_float2((float)sc, (float)((double)beta[j] - (double)mean[j] * sc));
         }
+        {   // split-fp16 weights
+            L.coutp32 = (L.cout + 31) / 32 * 32;
+            L.nchunks16 = (L.cin + KH - 1) / KH;
+            const size_t nh = (size_t)L.nchunks16 * 9 * L.coutp32 * KH;
+            std::vector<_Float16> wh(nh, (_Float16)0.0f), wl(nh, (_Float16)0.0f);
+            for (int j = 0; j < L.cout; j++)
+                for (int c = 0; c < L.cin; c++)
+                    for (int t = 0; t < 9; t++) {
+                        const float v = w[((size_t)j * L.cin + c) * 9 + t];
+                        const _Float16 h = (_Float16)v;
+                        const size_t o = (((size_t)(c / KH) * 9 + t) * L.coutp32 + j) * KH + (c % KH);
+                        wh[o] = h;
+                        wl[o] = (_Float16)((v - (float)h) * 2048.0f);
+                    }
+            std::vector<float> b32(L.coutp32, 0.0f);
+            memcpy(b32.data(), b, 4 * L.cout);
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_whi, nh * 2));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wlo, nh * 2));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias32, L.coutp32 * 4));
+            AIPT_HIP(ctx, hipMemcpy(L.d_whi, wh.data(), nh * 2, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMemcpy(L.d_wlo, wl.data(), nh * 2, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMemcpy(L.d_bias32, b32.data(), L.coutp32 * 4, hipMemcpyHostToDevice));
+        }
         AIPT_HIP(ctx, hipMalloc((void**)&L.d_w, wg.size() * 4));
         AIPT_HIP(ctx, hipMalloc((void**)&L.d_w_raw, (size_t)9 * L.cin * L.cout * 4));
         AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias, L.NP * 4));
@@ -683,7 +953,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
 
 int aipt_denoise_set_impl(aipt_ctx* ctx, int impl) {
     AIPT_CHECK_CTX(ctx);
-    if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
+    if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU && impl != AIPT_DN_IMPL_MFMA_F16X3) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
     state(ctx)->impl = impl;
     return AIPT_OK;
 }

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
     ap.add_argument("--bn", choices=["batch", "running"], default="batch")
     ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
+    ap.add_argument("--impl", choices=["f32", "f16x3"], default="f16x3",
+                    help="conv arithmetic: f32-input MFMA everywhere, or split-fp16 MFMA on the full-resolution levels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
@@ -84,6 +86,7 @@ def main():
     ctx.pathtrace_init(geoms, mats, faces, box if faces else None)
     ctx.load_weights(weight_blob)
     ctx.frame_configure(W, H)
+    ctx.denoise_set_impl(api.DN_IMPL_MFMA_F16X3 if args.impl == "f16x3" else api.DN_IMPL_MFMA)
     out = torch.empty(3, H, W, device=dev)
     bn_batch = args.bn == "batch"
     carry = args.hidden == "carry"

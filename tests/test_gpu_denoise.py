@@ -72,6 +72,25 @@ def test_against_oracle_small(ctx, bn_batch, carry, impl):
         assert err <= TOL, (bn_batch, carry, impl, j, err)
 
 
+@pytest.mark.parametrize("bn_batch", [True, False])
+def test_split_fp16_mfma_against_oracle(ctx, bn_batch):
+    """AIPT_DN_IMPL_MFMA_F16X3: the split-fp16 kernel runs the full-resolution levels (>= 200k pixels)."""
+    from oracle import DenoiseOracle
+    H, W = 384, 640
+    blob = synth.make_blob(21)
+    frames = [synth.make_gbuffer(H, W, 6, j) for j in range(2)]
+    outs = _run_gpu(ctx, blob, frames, H, W, bn_batch, True, api.DN_IMPL_MFMA_F16X3)
+    exact = _run_gpu(ctx, blob, frames, H, W, bn_batch, True, api.DN_IMPL_MFMA)
+    orc = DenoiseOracle(blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, bn_batch, j > 0)
+        e_split = np.abs(outs[j] - ref).max()
+        e_f32 = np.abs(exact[j] - ref).max()
+        assert e_split <= TOL and e_f32 <= TOL, (j, e_split, e_f32)
+        assert np.abs(outs[j] - exact[j]).max() <= TOL
+        print(f"frame {j}: split-fp16 err {e_split:.2e}, f32-MFMA err {e_f32:.2e}")
+
+
 def test_c1_size_256_against_oracle(ctx):
     # BASELINE.json configs[0] frame size
     from oracle import DenoiseOracle

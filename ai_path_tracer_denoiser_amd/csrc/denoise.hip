@@ -27,6 +27,7 @@ constexpr int KC = 8;            // input channels per LDS chunk (2 MFMA k-steps
 constexpr int NLAYERS = 28;
 constexpr float BN_EPS = 1e-5f;
 constexpr float SLOPE = 0.1f;
+constexpr int AIPT_DN_IMPL_MFMA_NOFEW = 99;   // (internal) disable the few-output kernel
 
 static const int ENC_CH[5] = {32, 43, 57, 76, 101};
 static const int DEC_CH[6] = {0, 3, 32, 43, 57, 76};
@@ -52,6 +53,7 @@ struct ConvArgs {
     int out_lrelu;
     float2* partial;     // [cout][nblk]
     int nblk;
+    int d2s;             // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to out[j][2y+a][2x+b]
 };
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
@@ -246,6 +248,13 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
                     v[q] = t;
                 }
                 if (jok && y < H) {
+                    if (g.d2s) {
+                        const int par = j / g.d2s, real = j - par * g.d2s;
+                        float* o = g.out + ((size_t)real * (2 * H) + 2 * y + (par >> 1)) * (2 * W) + (par & 1);
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (xb + q < W) { o[2 * (xb + q)] = v[q]; s1[n] += v[q]; s2[n] += v[q] * v[q]; }
+                    } else {
                     float* o = g.out + ((size_t)j * H + y) * W + xb;
                     if (vec_ok && xb + 3 < W) {
                         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -255,6 +264,7 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
 #pragma unroll
                         for (int q = 0; q < 4; q++)
                             if (xb + q < W) { o[q] = v[q]; s1[n] += v[q]; s2[n] += v[q] * v[q]; }
+                    }
                     }
                 }
             }
@@ -509,6 +519,94 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------- few-output conv
+// dec1.c1 (64 -> 3) and dec1.c2 (3 -> 3) have too few output channels for an MFMA N dimension (3 of 16/32 columns used).
+// Direct conv on the VALU instead: one thread per output pixel, COUT accumulators, input halo tile in LDS (already
+// normalised), weights read through the scalar cache (their index is wave-uniform).  Tile = 16 x 16 pixels, 16 input
+// channels per LDS chunk; for upsampled sources the LDS tile is the half-resolution 10 x 10 patch.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
+    constexpr int TS = 16, CK = 16;
+    __shared__ float tile[CK * 18 * 18];
+    __shared__ float2 red[4][COUT];
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS;
+    const int H = g.H, W = g.W;
+    const int up = g.a.up;
+    const int sh = up ? (H >> 1) : H, sw = up ? (W >> 1) : W;
+    // source-resolution patch covering the tile's 18 x 18 halo
+    const int py0 = up ? ((ty0 - 1) >> 1) : ty0 - 1, px0 = up ? ((tx0 - 1) >> 1) : tx0 - 1;   // arithmetic shift: -1 -> -1
+    const int PH = up ? 10 : 18, PW = up ? 10 : 18;
+    const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    float acc[COUT];
+#pragma unroll
+    for (int j = 0; j < COUT; j++) acc[j] = 0.f;
+    const int x = tx0 + lx, y = ty0 + ly;
+    for (int c0 = 0; c0 < ctot; c0 += CK) {
+        __syncthreads();
+        for (int e = tid; e < CK * PH * PW; e += 256) {
+            const int c = e / (PH * PW), rem = e - c * (PH * PW);
+            const int yy = rem / PW, xx = rem - yy * PW;
+            const int sy = py0 + yy, sx = px0 + xx, cg = c0 + c;
+            float v = 0.f;
+            if (cg < ctot && sy >= 0 && sy < sh && sx >= 0 && sx < sw) {
+                const ConvSrc& src = cg < aC ? g.a : g.b;
+                const int ch = cg < aC ? cg : cg - aC;
+                v = src.p[((size_t)ch * sh + sy) * sw + sx];
+                if (src.ab) { const float2 ab = src.ab[ch]; v = fmaf(ab.x, v, ab.y); }
+                v = lrelu(v, src.slope);
+            }
+            tile[e] = v;
+        }
+        __syncthreads();
+        const int cn = ctot - c0 < CK ? ctot - c0 : CK;
+        for (int c = 0; c < cn; c++) {
+            const float* wk = g.w_raw + (size_t)(c0 + c) * 9;      // + j*cin*9 per output channel; wave-uniform
+            const float* tp = tile + c * (PH * PW);
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                const int yy = y + ky - 1;
+                const int ry = (up ? (yy >> 1) : yy) - py0;
+                const bool yin = yy >= 0 && yy < H;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const int xx = x + kx - 1;
+                    const int rx = (up ? (xx >> 1) : xx) - px0;
+                    // out-of-image taps are zero in the NORMALISED domain (the patch already holds 0 there for the
+                    // source-resolution border; at full resolution an odd border pixel maps inside the patch)
+                    const float v = (yin && xx >= 0 && xx < W) ? tp[ry * PW + rx] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < COUT; j++) acc[j] = fmaf(v, wk[(size_t)j * g.cin * 9 + ky * 3 + kx], acc[j]);
+                }
+            }
+        }
+    }
+    float s1[COUT], s2[COUT];
+    const bool ok = x < W && y < H;
+#pragma unroll
+    for (int j = 0; j < COUT; j++) {
+        float t = acc[j] + g.bias[j];
+        if (g.out_lrelu) t = lrelu(t, SLOPE);
+        if (ok && j < g.cout) g.out[((size_t)j * H + y) * W + x] = t;
+        s1[j] = ok ? t : 0.f; s2[j] = ok ? t * t : 0.f;
+    }
+    if (g.partial) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < COUT; j++) {
+            float a = s1[j], b = s2[j];
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (lane == 0) red[wave][j] = make_float2(a, b);
+        }
+        __syncthreads();
+        if (tid < COUT && tid < g.cout) {
+            float2 t = red[0][tid];
+            for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
+            g.partial[(size_t)tid * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- VALU conv
 // One thread per output element; reads its 9*cin taps straight from HBM.  Only for on-GPU cross-checks.
 __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
@@ -549,17 +647,20 @@ __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, 
 // One block per channel: fixed-order fp64 tree over the conv blocks' partials -> (a, b).  running != nullptr copies
 // the precomputed running-statistics affine instead.
 __global__ __launch_bounds__(256) void bn_finalize(const float2* partial, int nblk, double inv_n, const float* gamma,
-                                                   const float* beta, const float2* running, float2* ab) {
+                                                   const float* beta, const float2* running, float2* ab, int groups,
+                                                   int gstride) {
     const int c = blockIdx.x;
     if (running) {
         if (threadIdx.x == 0) ab[c] = running[c];
         return;
     }
+    // channel c owns `groups` rows of the partial table (depth-to-space convs: one row per output parity)
     double a = 0, b = 0;
-    for (int i = threadIdx.x; i < nblk; i += 256) {
-        const float2 p = partial[(size_t)c * nblk + i];
-        a += p.x; b += p.y;
-    }
+    for (int gi = 0; gi < groups; gi++)
+        for (int i = threadIdx.x; i < nblk; i += 256) {
+            const float2 p = partial[(size_t)(c + gi * gstride) * nblk + i];
+            a += p.x; b += p.y;
+        }
     __shared__ double sa[256], sb[256];
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
@@ -617,6 +718,7 @@ struct LayerW {
     float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
     float2* d_ab_running = nullptr;
     // split-fp16 copy of the weights for conv3x3_f16x3: [nchunks16][9][coutp32][16] hi and lo*2^11
+    float *d_w_d2s = nullptr, *d_bias_d2s = nullptr;   // upsample+conv as a half-resolution conv with 4*cout virtual channels
     int coutp32 = 0, nchunks16 = 0;
     _Float16 *d_whi = nullptr, *d_wlo = nullptr;
     float* d_bias32 = nullptr;
@@ -672,6 +774,7 @@ static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
         hipFree(l.d_ab_running); hipFree(l.d_whi); hipFree(l.d_wlo); hipFree(l.d_bias32);
+        hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s);
         l = LayerW();
     }
     s->have_weights = false;
@@ -747,10 +850,11 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
     g.nchunks = (g.a.C + g.b.C + KC - 1) / KC;
     g.out = dst.p; g.out_lrelu = out_lrelu;
+    g.d2s = 0;
     if (B && use_b && upA != upB) return fail(ctx, AIPT_E_STATE, "layer %d: concat sources must share the resampling mode", li);
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin) return fail(ctx, AIPT_E_STATE, "layer %d: %d input channels wired, %d expected", li, expect, L.cin);
-    int nblk = 1;
+    int nblk = 1, fin_groups = 1, fin_stride = 0;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], ctx->stream));
@@ -760,6 +864,31 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, s->partial);
+    } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
+        // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
+        g.a.up = 0; g.b.up = 0;
+        g.H = H / 2; g.W = W / 2;
+        g.w = L.d_w_d2s; g.bias = L.d_bias_d2s;
+        g.cout = 4 * L.cout; g.NP = 16; g.d2s = L.cout;
+        const TileChoice t = choose_tile(g.H, g.W, 1);
+        nblk = conv_nblk(t, g.H, g.W);
+        if ((size_t)nblk * g.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        g.partial = batch ? s->partial : nullptr;
+        g.nblk = nblk;
+        fin_groups = 4; fin_stride = L.cout;
+        const dim3 grid((g.W + 16 * t.mbx - 1) / (16 * t.mbx), (g.H + 4 * t.rw - 1) / (4 * t.rw), 1);
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,1>", t.rw, t.mbx);
+        if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, ctx->stream);
+        else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, ctx->stream);
+        else launch_mfma<1, 1, 1>(g, grid, ctx->stream);
+    } else if (L.cout == 3 && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
+        const dim3 grid((W + 15) / 16, (H + 15) / 16);
+        nblk = grid.x * grid.y;
+        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        g.partial = batch ? s->partial : nullptr;
+        g.nblk = nblk;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
+        hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
     } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= 200000 && H % 8 == 0) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
@@ -797,7 +926,8 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     }
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], ctx->stream));
     hipLaunchKernelGGL(bn_finalize, dim3(L.cout), dim3(256), 0, ctx->stream, s->partial, nblk,
-                       1.0 / ((double)H * (double)W), L.d_gamma, L.d_beta, batch ? nullptr : L.d_ab_running, dst.ab);
+                       1.0 / ((double)H * (double)W), L.d_gamma, L.d_beta, batch ? nullptr : L.d_ab_running, dst.ab,
+                       fin_groups, fin_stride);
     AIPT_HIP(ctx, hipGetLastError());
     return AIPT_OK;
 }
@@ -856,6 +986,31 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         for (int j = 0; j < L.cout; j++) {
             const double sc = (double)gamma[j] / sqrt((double)var[j] + (double)BN_EPS);
             abr[j] = make_float2((float)sc, (float)((double)beta[j] - (double)mean[j] * sc));
+        }
+        if (i == 26) {
+            // dec1.c1 = conv3x3(upsample2(x)) with 3 outputs: as a plain conv on the half-resolution x with 12 virtual
+            // channels v = (2a+b)*3 + j, one per output parity (a,b); W'[v][c][dy][dx] = sum of the taps (ky,kx) whose
+            // upsampled source row/col floor((a+ky-1)/2), floor((b+kx-1)/2) is dy-1, dx-1.  Zero padding is equivalent.
+            const int vco = 4 * L.cout, vnp = (vco + 15) / 16 * 16;
+            std::vector<float> wv((size_t)L.nchunks * 9 * KC * vnp, 0.0f), bv(vnp, 0.0f);
+            for (int par = 0; par < 4; par++) {
+                const int a = par >> 1, bb = par & 1;
+                for (int j = 0; j < L.cout; j++) {
+                    const int v = par * L.cout + j;
+                    bv[v] = b[j];
+                    for (int c = 0; c < L.cin; c++)
+                        for (int ky = 0; ky < 3; ky++)
+                            for (int kx = 0; kx < 3; kx++) {
+                                const int dy = (a + ky + 1) / 2 - 1, dx = (bb + kx + 1) / 2 - 1;   // floor((a+ky-1)/2)
+                                wv[(((size_t)(c / KC) * 9 + (dy + 1) * 3 + (dx + 1)) * KC + (c % KC)) * vnp + v] +=
+                                    w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx];
+                            }
+                }
+            }
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_w_d2s, wv.size() * 4));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias_d2s, vnp * 4));
+            AIPT_HIP(ctx, hipMemcpy(L.d_w_d2s, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMemcpy(L.d_bias_d2s, bv.data(), vnp * 4, hipMemcpyHostToDevice));
         }
         {   // split-fp16 weights
             L.coutp32 = (L.cout + 31) / 32 * 32;

@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaiptd.so")
 
 # flags (include/aiptd.h)
-TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0 = 1, 2, 4
+TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0, TRACE_BRUTE_FORCE = 1, 2, 4, 8
 TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
 DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
 DN_IMPL_MFMA, DN_IMPL_VALU, DN_IMPL_MFMA_F16X3 = 0, 1, 2
@@ -245,7 +245,12 @@ class Context:
         """pathtraceInit(Scene*): upload the scene; allocate path state for width x height."""
         ga = (Geom * max(1, len(geoms)))(*geoms)
         ma = (Material * max(1, len(materials)))(*materials)
-        fa = (Face * max(1, len(faces)))(*faces)
+        if isinstance(faces, np.ndarray):                      # structured array with the 76-byte Face layout
+            assert faces.dtype.itemsize == 76
+            keep = np.ascontiguousarray(faces)
+            fa = keep.ctypes.data_as(_P)
+        else:
+            fa = (Face * max(1, len(faces)))(*faces)
         box = mesh_box if mesh_box is not None else AABB()
         self._ck(lib().aipt_scene_upload(self._h, ga, len(geoms), ma, len(materials),
                                          fa if len(faces) else None, len(faces),

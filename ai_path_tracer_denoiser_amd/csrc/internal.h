@@ -48,6 +48,15 @@ void set_global_error(const char* msg);
 #define AIPT_CHECK_CTX(ctx) \
     do { if (!(ctx)) return AIPT_E_INVALID; } while (0)
 
+// threaded BVH node (bvh.cpp): DFS order; leaf = (first_leaf_face << 3) | count, or -1 for an inner node
+struct BvhNode {
+    float lo[3];
+    int skip;
+    float hi[3];
+    int leaf;
+};
+void build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);
+
 void trace_destroy(aipt_ctx* ctx);
 void denoise_destroy(aipt_ctx* ctx);
 

@@ -41,6 +41,9 @@ struct TraceState {
     DevGeom* d_geoms = nullptr; int ngeoms = 0;
     aipt_material* d_mats = nullptr; int nmats = 0;
     DevFace* d_faces = nullptr; int nfaces = 0;
+    BvhNode* d_nodes = nullptr; int nnodes = 0;     // threaded BVH over the faces (bvh.cpp)
+    DevFace* d_lfaces = nullptr;                    // faces in leaf order
+    int* d_lidx = nullptr;                          // their original indices (tie-break + parity with the index-ordered loop)
     aipt_aabb box{};
     bool have_scene = false;
     int W = 0, H = 0, P = 0, nblk = 0;
@@ -62,6 +65,8 @@ struct TraceParams {
     const DevGeom* geoms; int ngeoms;
     const aipt_material* mats;
     const DevFace* faces; int nfaces;
+    const BvhNode* nodes; int nnodes;
+    const DevFace* lfaces; const int* lidx;
     aipt_aabb box;
     float* gbuf; size_t plane; int stride;
     const int* cnt_in; int* cnt_out;
@@ -394,10 +399,44 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
         }
         if (p.nfaces && rayAABB(o, d, p.box)) {                                  // RAY_CULLING true (:23, :258)
-            for (int fi = 0; fi < p.nfaces; fi++) {
-                v3 tp, tn;
-                const float t = triangleTest(p.faces[fi], o, d, tp, tn);
-                if (t > 0.0f && t_min > t) { t_min = t; materialid = p.faces[fi].materialid; hitP = tp; normal = tn; }
+            if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
+                // the reference's loop: every face, in index order
+                for (int fi = 0; fi < p.nfaces; fi++) {
+                    v3 tp, tn;
+                    const float t = triangleTest(p.faces[fi], o, d, tp, tn);
+                    if (t > 0.0f && t_min > t) { t_min = t; materialid = p.faces[fi].materialid; hitP = tp; normal = tn; }
+                }
+            } else {
+                // threaded BVH: same triangle test on the candidate faces.  The index-ordered loop keeps the FIRST face
+                // among equal distances and never lets a face replace a primitive at equal distance; best_face
+                // reproduces exactly that, so the result is the brute-force result.
+                const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+                int best_face = -1;
+                int ni = 0;
+                while (ni < p.nnodes) {
+                    const BvhNode nd = p.nodes[ni];
+                    const float t1 = (nd.lo[0] - o.x) * ix, t2 = (nd.hi[0] - o.x) * ix;
+                    const float t3 = (nd.lo[1] - o.y) * iy, t4 = (nd.hi[1] - o.y) * iy;
+                    const float t5 = (nd.lo[2] - o.z) * iz, t6 = (nd.hi[2] - o.z) * iz;
+                    const float tnear = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+                    const float tfar = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+                    if (tfar < 0.0f || tnear > tfar || tnear > t_min) { ni = nd.skip; continue; }   // NaN -> visit
+                    if (nd.leaf >= 0) {
+                        const int first = nd.leaf >> 3, cnt = nd.leaf & 7;
+                        for (int k = 0; k < cnt; k++) {
+                            v3 tp, tn;
+                            const float t = triangleTest(p.lfaces[first + k], o, d, tp, tn);
+                            const int fi = p.lidx[first + k];
+                            if (t > 0.0f && (t_min > t || (t_min == t && best_face >= 0 && fi < best_face))) {
+                                t_min = t; materialid = p.lfaces[first + k].materialid; hitP = tp; normal = tn;
+                                best_face = fi;
+                            }
+                        }
+                        ni = nd.skip;
+                    } else {
+                        ni = ni + 1;
+                    }
+                }
             }
         }
         const bool hit = materialid != -1;
@@ -464,7 +503,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
 void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces);
+    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0);
     delete s;
     ctx->trace = nullptr;
@@ -496,8 +535,9 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     TraceState* s = tstate(ctx);
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces);
+    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
+    s->d_nodes = nullptr; s->d_lfaces = nullptr; s->d_lidx = nullptr; s->nnodes = 0;
     std::vector<DevGeom> dg(ngeoms);
     for (int i = 0; i < ngeoms; i++) {
         dg[i].type = geoms[i].type; dg[i].materialid = geoms[i].materialid;
@@ -513,6 +553,20 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_faces, sizeof(DevFace) * (nfaces ? nfaces : 1)));
     if (nfaces) AIPT_HIP(ctx, hipMemcpy(s->d_faces, faces, sizeof(DevFace) * nfaces, hipMemcpyHostToDevice));
     if (nfaces) s->box = *mesh_box; else memset(&s->box, 0, sizeof(s->box));
+    if (nfaces) {
+        std::vector<BvhNode> nodes;
+        std::vector<int> lidx;
+        build_bvh(faces, nfaces, nodes, lidx);
+        std::vector<DevFace> lf(lidx.size());
+        for (size_t i = 0; i < lidx.size(); i++) memcpy(&lf[i], &faces[lidx[i]], sizeof(DevFace));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(BvhNode) * nodes.size()));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_lfaces, sizeof(DevFace) * lf.size()));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_lidx, sizeof(int) * lidx.size()));
+        AIPT_HIP(ctx, hipMemcpy(s->d_nodes, nodes.data(), sizeof(BvhNode) * nodes.size(), hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(s->d_lfaces, lf.data(), sizeof(DevFace) * lf.size(), hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(s->d_lidx, lidx.data(), sizeof(int) * lidx.size(), hipMemcpyHostToDevice));
+        s->nnodes = (int)nodes.size();
+    }
     s->ngeoms = ngeoms; s->nmats = nmaterials; s->nfaces = nfaces;
     s->have_scene = true;
     return AIPT_OK;
@@ -522,8 +576,9 @@ int aipt_scene_free(aipt_ctx* ctx) {
     AIPT_CHECK_CTX(ctx);
     AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     TraceState* s = tstate(ctx);
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces);
+    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
+    s->d_nodes = nullptr; s->d_lfaces = nullptr; s->d_lidx = nullptr; s->nnodes = 0;
     return AIPT_OK;
 }
 
@@ -567,6 +622,7 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     p.st = s->d_state;
     p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats;
     p.faces = s->d_faces; p.nfaces = s->nfaces; p.box = s->box;
+    p.nodes = s->d_nodes; p.nnodes = s->nnodes; p.lfaces = s->d_lfaces; p.lidx = s->d_lidx;
     p.gbuf = d_gbuf; p.plane = (size_t)gbuf_rows * gbuf_stride; p.stride = gbuf_stride;
     p.n_live = s->d_nlive;
     p.mat0 = (flags & AIPT_TRACE_RECORD_MAT0) ? s->d_mat0 : nullptr;

@@ -97,3 +97,136 @@ def make_gbuffer(H, W, seed=0, frame=0):
     miss = uniform01(n, seed, s + 9) < np.float32(0.10)
     g[:, miss] = 0
     return g.reshape(10, H, W)
+
+
+# --------------------------------------------------------------------------------------------- procedural meshes
+# The reference's mesh scenes point at OBJ files that do not ship (Sponza / living room exist only as GIFs),
+# so the mesh configurations use seeded procedural stand-ins with a stated triangle count.
+
+FACE_DTYPE = np.dtype([("v", np.float32, (3, 3)), ("n", np.float32, (3, 3)), ("materialid", np.int32)])   # Face, 76 B
+assert FACE_DTYPE.itemsize == 76
+
+
+def _grid_surface(fn, nu, nv, material, flip=False):
+    """Tessellate a parametric surface (u,v in [0,1]) -> (position, normal) into 2*nu*nv smooth-shaded triangles,
+    counter-clockwise seen from the side the normal points to (the reference culls back faces, intersect.inl:51-53)."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    pos, nrm = fn(uu, vv)                                   # [nu+1, nv+1, 3]
+    nrm = nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)
+    i, j = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    i, j = i.ravel(), j.ravel()
+    quads = [(i, j), (i + 1, j), (i + 1, j + 1), (i, j + 1)]
+    tris = [(0, 1, 2), (0, 2, 3)] if not flip else [(0, 2, 1), (0, 3, 2)]
+    faces = np.zeros(2 * nu * nv, FACE_DTYPE)
+    for t, tri in enumerate(tris):
+        for k, corner in enumerate(tri):
+            a, b = quads[corner]
+            faces["v"][t::2, k] = pos[a, b]
+            faces["n"][t::2, k] = nrm[a, b]
+    faces["materialid"] = material
+    # fix the winding so the geometric normal agrees with the shading normal
+    e1 = faces["v"][:, 1] - faces["v"][:, 0]
+    e2 = faces["v"][:, 2] - faces["v"][:, 0]
+    gn = np.cross(e1.astype(np.float64), e2.astype(np.float64))
+    bad = (gn * faces["n"][:, 0].astype(np.float64)).sum(-1) < 0
+    faces["v"][bad] = faces["v"][bad][:, [0, 2, 1]]
+    faces["n"][bad] = faces["n"][bad][:, [0, 2, 1]]
+    return faces
+
+
+def make_atrium_mesh(n_triangles=262144, seed=565, material=1):
+    """"Sponza-like" atrium inside the 10 x 10 x 10 Cornell volume: two rows of columns, arches between neighbouring
+    columns, a gently rippled floor slab and a few spheres.  Returns (faces[FACE_DTYPE], lb[3], ub[3]) with exactly
+    n_triangles triangles (the floor grid absorbs the remainder).  Deterministic for a given (n_triangles, seed)."""
+    assert n_triangles >= 2048
+    rng_u = uniform01(64, seed, 9001).astype(np.float64)
+    parts = []
+    ncol = 6
+    budget = n_triangles
+    col_tris = int(budget * 0.45 / (2 * ncol))
+    arch_tris = int(budget * 0.30 / (2 * (ncol - 1)))
+    sph_tris = int(budget * 0.10 / 3)
+
+    def dims(target):                                           # nu, nv with 2*nu*nv <= target, nu ~ 2*nv
+        nv = max(2, int(np.sqrt(target / 4.0)))
+        nu = max(3, target // (2 * nv))
+        return nu, nv
+
+    xs = np.linspace(-3.6, 3.6, ncol)
+    for row, z in enumerate((-2.6, 1.4)):
+        for ci, x in enumerate(xs):
+            r = 0.28 + 0.06 * rng_u[row * ncol + ci]
+            nu, nv = dims(col_tris)
+
+            def col(u, v, x=x, z=z, r=r):
+                ang = 2 * np.pi * u
+                bulge = 1.0 + 0.08 * np.sin(np.pi * v) + 0.03 * np.cos(8 * ang)
+                p = np.stack([x + r * bulge * np.cos(ang), 0.02 + 6.0 * v, z + r * bulge * np.sin(ang)], -1)
+                n = np.stack([np.cos(ang), -0.08 * np.pi * np.cos(np.pi * v) * r / 6.0, np.sin(ang)], -1)
+                return p, n
+            parts.append(_grid_surface(col, nu, nv, material))
+        for ci in range(ncol - 1):
+            x0, x1 = xs[ci], xs[ci + 1]
+            nu, nv = dims(arch_tris)
+
+            def arch(u, v, x0=x0, x1=x1, z=z):
+                th = np.pi * u                                  # along the arch
+                ph = 2 * np.pi * v                              # around the tube
+                R, rt = 0.5 * (x1 - x0), 0.16
+                cx, cy = 0.5 * (x0 + x1), 6.0
+                dirx, diry = -np.cos(th), np.sin(th)            # centre-line direction from the arch centre
+                p = np.stack([cx + (R + rt * np.cos(ph)) * dirx, cy + (R + rt * np.cos(ph)) * diry,
+                              z + rt * np.sin(ph)], -1)
+                n = np.stack([np.cos(ph) * dirx, np.cos(ph) * diry, np.sin(ph)], -1)
+                return p, n
+            parts.append(_grid_surface(arch, nu, nv, material))
+    for si in range(3):
+        cx, cz = -2.5 + 2.5 * si, -0.6 + 0.5 * rng_u[40 + si]
+        rad = 0.55 + 0.2 * rng_u[44 + si]
+        nu, nv = dims(sph_tris)
+
+        def sph(u, v, cx=cx, cz=cz, rad=rad):
+            ang, pol = 2 * np.pi * u, np.pi * (0.02 + 0.96 * v)
+            n = np.stack([np.sin(pol) * np.cos(ang), np.cos(pol), np.sin(pol) * np.sin(ang)], -1)
+            return np.array([cx, rad + 0.05, cz]) + rad * n, n
+        parts.append(_grid_surface(sph, nu, nv, material))
+    used = sum(len(p) for p in parts)
+    rest = n_triangles - used
+    assert rest >= 2 and rest % 2 == 0, (n_triangles, used)
+    # floor slab: nu x nv grid with 2*nu*nv == rest exactly (factor rest/2)
+    half = rest // 2
+    nu = int(np.sqrt(half))
+    while half % nu:
+        nu -= 1
+    nv = half // nu
+
+    def floor(u, v):
+        x, z = -4.6 + 9.2 * u, -4.6 + 9.2 * v
+        y = 0.03 + 0.015 * np.sin(3.0 * x) * np.cos(2.5 * z)
+        dydx = 0.015 * 3.0 * np.cos(3.0 * x) * np.cos(2.5 * z)
+        dydz = -0.015 * 2.5 * np.sin(3.0 * x) * np.sin(2.5 * z)
+        return np.stack([x, y, z], -1), np.stack([-dydx, np.ones_like(x), -dydz], -1)
+    parts.append(_grid_surface(floor, nu, nv, material))
+    faces = np.concatenate(parts)
+    assert len(faces) == n_triangles
+    verts = faces["v"].reshape(-1, 3)
+    lb = verts.min(axis=0)
+    # Scene::loadObj starts the upper bound at FLT_MIN, the smallest positive float (scene.cpp:216-218)
+    ub = np.maximum(verts.max(axis=0), np.float32(np.finfo(np.float32).tiny))
+    return faces, lb.astype(np.float32), ub.astype(np.float32)
+
+
+def write_obj(path, faces):
+    """Write faces as a Wavefront OBJ (v / vn / f a//a) for the scene-file front end (MESH blocks)."""
+    with open(path, "w") as f:
+        for fa in faces:
+            for k in range(3):
+                f.write("v %.9g %.9g %.9g\n" % tuple(fa["v"][k]))
+        for fa in faces:
+            for k in range(3):
+                f.write("vn %.9g %.9g %.9g\n" % tuple(fa["n"][k]))
+        for i in range(len(faces)):
+            a = 3 * i + 1
+            f.write(f"f {a}//{a} {a + 1}//{a + 1} {a + 2}//{a + 2}\n")

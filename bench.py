@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--depth", type=int, default=8)
     ap.add_argument("--scene", default=os.path.join(ROOT, "scenes", "cornell.txt"))
+    ap.add_argument("--mesh", type=int, default=0, metavar="NTRI",
+                    help="add the procedural Sponza-like atrium mesh with NTRI triangles (BASELINE configs[2]: 262144)")
     ap.add_argument("--bn", choices=["batch", "running"], default="batch")
     ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
     ap.add_argument("--impl", choices=["f32", "f16x3"], default="f16x3",
@@ -73,7 +75,17 @@ def main():
     cam_bytes = None
     if rank == 0:
         sc = api.Scene(args.scene, res=(W, H), depth=depth)
-        scene_blob = adist.pack_scene(sc.geoms, sc.materials, sc.faces, sc.mesh_box if sc.nfaces else None)
+        geoms0, mats0, faces0, box0 = sc.geoms, sc.materials, sc.faces, (sc.mesh_box if sc.nfaces else None)
+        if args.mesh:
+            stone = api.Material()
+            stone.color[:] = [.75, .7, .6]                      # all-diffuse stone
+            mats0 = list(mats0) + [stone]
+            fnp, lb, ub = synth.make_atrium_mesh(args.mesh, 565, material=len(mats0) - 1)
+            faces0 = [api.Face.from_buffer_copy(fnp[i].tobytes()) for i in range(len(fnp))]
+            box0 = api.AABB()
+            box0.lb[:] = [float(v) for v in lb]
+            box0.ub[:] = [float(v) for v in ub]
+        scene_blob = adist.pack_scene(geoms0, mats0, faces0, box0)
         weight_blob = synth.make_blob(565)
         cam_bytes = bytes(sc.camera) + np.array([sc.zoom, sc.phi, sc.theta], np.float32).tobytes()
     scene_blob = adist.broadcast_bytes(scene_blob, 0, dev)
@@ -204,8 +216,10 @@ def main():
             "metric": "denoised frames/sec @1280x720 1spp depth8", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Cornell box (7 primitives, no mesh) {W}x{H}, 1spp, depth {depth}, orbit pan, "
-                                   f"BN {args.bn}-stats, hidden {args.hidden}",
+            "config": {"workload": (f"Cornell box (7 primitives, no mesh)" if not args.mesh else
+                                    f"Cornell walls + procedural Sponza-like atrium mesh ({args.mesh} triangles, BVH)")
+                                   + f" {W}x{H}, 1spp, depth {depth}, orbit pan, BN {args.bn}-stats, hidden {args.hidden}, "
+                                   f"conv {args.impl}",
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}"},
             "roofline": roof,

@@ -119,6 +119,8 @@ int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
                                        bounce b is seeded with the path's rank among the live paths, as thrust::partition
                                        leaves it (pathtrace.cu:351,505).  Without it the seed index is the pixel index. */
 #define AIPT_TRACE_RECORD_MAT0 4u   /* also record the first-hit material id per pixel (integer parity channel) */
+#define AIPT_TRACE_BRUTE_FORCE 8u   /* mesh: test every face in index order like the reference (pathtrace.cu:258-269) instead
+                                       of walking the BVH built at upload; same result, for parity checks and timing */
 #define AIPT_TRACE_DEFAULT     (AIPT_TRACE_AA | AIPT_TRACE_COMPACT)
 
 /* pathtraceInit (pathtrace.cu:96-129), scene part: copies and re-lays-out the scene on the device.

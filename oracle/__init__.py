@@ -271,10 +271,24 @@ class OracleScene:
         """runCuda() camera rebuild (main.cpp:122-140)."""
         _trace_lib().orc_camera_orbit(C.byref(self.camera), C.c_float(zoom), C.c_float(phi), C.c_float(theta))
 
+    def set_mesh(self, faces_np, lb, ub):
+        """Attach a mesh given as a numpy structured array with the 76-byte Face layout (synth.FACE_DTYPE)."""
+        assert faces_np.dtype.itemsize == 76
+        self.faces_np = np.ascontiguousarray(faces_np)
+        self.mesh_box.lb[:] = [float(v) for v in lb]
+        self.mesh_box.ub[:] = [float(v) for v in ub]
+
+    @property
+    def nfaces(self):
+        return len(self.faces_np) if getattr(self, "faces_np", None) is not None else len(self.faces)
+
     def arrays(self):
         ga = (Geom * max(1, len(self.geoms)))(*self.geoms)
         ma = (Material * max(1, len(self.materials)))(*self.materials)
-        fa = (Face * max(1, len(self.faces)))(*self.faces)
+        if getattr(self, "faces_np", None) is not None:
+            fa = self.faces_np.ctypes.data_as(C.c_void_p)
+        else:
+            fa = (Face * max(1, len(self.faces)))(*self.faces)
         return ga, ma, fa
 
     def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True):
@@ -288,6 +302,6 @@ class OracleScene:
         mat0 = np.full(W * H, -2, np.int32)
         ga, ma, fa = self.arrays()
         nb = L.orc_pathtrace(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
-                             len(self.faces), C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
+                             self.nfaces, C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
                              n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None)
         return gbuf, n_live[:nb + 1], mat0

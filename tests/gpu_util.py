@@ -13,10 +13,22 @@ def to_api_scene(sc):
     """oracle.OracleScene -> api structs (same bytes; the PODs share the reference's layout)."""
     geoms = [api.Geom.from_buffer_copy(bytes(g)) for g in sc.geoms]
     mats = [api.Material.from_buffer_copy(bytes(m)) for m in sc.materials]
-    faces = [api.Face.from_buffer_copy(bytes(f)) for f in sc.faces]
+    if getattr(sc, "faces_np", None) is not None:
+        faces = sc.faces_np
+    else:
+        faces = [api.Face.from_buffer_copy(bytes(f)) for f in sc.faces]
     box = api.AABB.from_buffer_copy(bytes(sc.mesh_box))
     cam = api.Camera.from_buffer_copy(bytes(sc.camera))
     return geoms, mats, faces, box, cam
+
+
+def add_stone_material(sc):
+    """append the diffuse 'stone' material of the mesh scenes (RGB .75 .7 .6) and return its id"""
+    import oracle
+    m = oracle.Material()
+    m.color[:] = [.75, .7, .6]
+    sc.materials.append(m)
+    return len(sc.materials) - 1
 
 
 def gpu_trace(ctx, sc, depth, rows=None, stride=None, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0):

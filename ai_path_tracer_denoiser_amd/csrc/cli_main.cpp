@@ -1,0 +1,316 @@
+// aiptd -- command-line front end over the C ABI (include/aiptd.h).
+//
+// Keeps the reference's CLI surface: `cis565_path_tracer SCENEFILE.txt` (Inference/src/main.cpp:47-58) becomes
+// `aiptd SCENEFILE.txt [options]`; instead of a GLFW window (out of scope) it renders a frame sequence
+// along an orbit pan and writes the 10-channel G-buffer + denoised RGB per frame in the data-gen
+// directory convention of Inference/train.sh:13-27 (RGB/ Normals/ Depth/ Albedos/ + Denoised/), 8-bit PNGs scaled as
+// training/preprocess.py:37-41 un-scales them (colours x255, normals x100, depth x10), and optionally raw .npy tensors.
+//
+//   aiptd scene.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE | --synthetic-weights SEED]
+//                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3] [--pan AMPLITUDE] [--device I]
+//                   [--no-aa] [--no-compaction] [--dump-weights FILE]
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "../../include/aiptd.h"
+
+namespace {
+
+// ---- deterministic synthetic weights: byte-identical to ai_path_tracer_denoiser_amd/synth.py make_blob()
+uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+float uniform01(uint64_t idx, uint64_t seed, uint64_t stream) {
+    const uint64_t gold = 0x9E3779B97F4A7C15ull;
+    const uint64_t key = mix64(seed * gold + stream);
+    const uint64_t h = mix64(idx * gold + key);
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+void layer_table(int* cin, int* cout) {
+    static const int enc[5] = {32, 43, 57, 76, 101}, dec[6] = {0, 3, 32, 43, 57, 76};
+    int n = 0, c_in = 10;
+    for (int i = 0; i < 5; i++) {
+        cin[n] = c_in; cout[n++] = enc[i];
+        cin[n] = 2 * enc[i]; cout[n++] = enc[i];
+        cin[n] = enc[i]; cout[n++] = enc[i];
+        c_in = enc[i];
+    }
+    cin[n] = 101; cout[n++] = 101; cin[n] = 202; cout[n++] = 101; cin[n] = 101; cout[n++] = 101;
+    int prev = 101;
+    for (int k = 5; k >= 1; k--) {
+        cin[n] = prev + enc[k - 1]; cout[n++] = dec[k];
+        cin[n] = dec[k]; cout[n++] = dec[k];
+        prev = dec[k];
+    }
+}
+std::vector<unsigned char> make_synth_blob(uint64_t seed) {
+    int cin[28], cout[28];
+    layer_table(cin, cout);
+    std::vector<unsigned char> out;
+    auto put = [&](const void* p, size_t n) { out.insert(out.end(), (const unsigned char*)p, (const unsigned char*)p + n); };
+    put("AIPTDW01", 8);
+    const uint32_t hdr[2] = {28, 0};
+    put(hdr, 8);
+    for (int l = 0; l < 28; l++) { const uint32_t cc[2] = {(uint32_t)cin[l], (uint32_t)cout[l]}; put(cc, 8); }
+    for (int l = 0; l < 28; l++) {
+        const int fan_in = cin[l] * 9;
+        const float bound = std::sqrt(6.0f / (float)fan_in);
+        const size_t nw = (size_t)cout[l] * cin[l] * 9;
+        std::vector<float> w(nw);
+        for (size_t i = 0; i < nw; i++) w[i] = (uniform01(i, seed, 16 * l + 0) - 0.5f) * 2.0f * bound;
+        put(w.data(), 4 * nw);
+        std::vector<float> v(cout[l]);
+        for (int j = 0; j < cout[l]; j++) v[j] = 0.01f;
+        put(v.data(), 4 * cout[l]);                                                           // bias
+        for (int j = 0; j < cout[l]; j++) {
+            const float g = 0.5f + uniform01(j, seed, 16 * l + 1);
+            v[j] = g * (uniform01(j, seed, 16 * l + 2) < 0.1f ? -1.0f : 1.0f);
+        }
+        put(v.data(), 4 * cout[l]);                                                           // gamma
+        for (int j = 0; j < cout[l]; j++) v[j] = (uniform01(j, seed, 16 * l + 3) - 0.5f) * 0.4f;
+        put(v.data(), 4 * cout[l]);                                                           // beta
+        for (int j = 0; j < cout[l]; j++) v[j] = (uniform01(j, seed, 16 * l + 4) - 0.5f) * 0.2f;
+        put(v.data(), 4 * cout[l]);                                                           // running mean
+        for (int j = 0; j < cout[l]; j++) v[j] = 0.5f + uniform01(j, seed, 16 * l + 5);
+        put(v.data(), 4 * cout[l]);                                                           // running var
+    }
+    return out;
+}
+
+// ---- minimal PNG writer (8-bit gray / RGB, zlib "stored" blocks: no compression library in the image)
+uint32_t crc_table[256];
+void crc_init() {
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_table[n] = c;
+    }
+}
+uint32_t crc32(const unsigned char* p, size_t n, uint32_t c = 0xFFFFFFFFu) {
+    for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c;
+}
+void be32(std::vector<unsigned char>& v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((x >> s) & 0xFF); }
+void chunk(std::vector<unsigned char>& png, const char* type, const std::vector<unsigned char>& data) {
+    be32(png, (uint32_t)data.size());
+    std::vector<unsigned char> td(type, type + 4);
+    td.insert(td.end(), data.begin(), data.end());
+    png.insert(png.end(), td.begin(), td.end());
+    be32(png, crc32(td.data(), td.size()) ^ 0xFFFFFFFFu);
+}
+bool write_png(const std::string& path, const unsigned char* px, int w, int h, int channels) {
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * (w * channels + 1));
+    for (int y = 0; y < h; y++) {
+        raw.push_back(0);                                                                     // filter: none
+        raw.insert(raw.end(), px + (size_t)y * w * channels, px + (size_t)(y + 1) * w * channels);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (unsigned char c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    for (size_t off = 0; off < raw.size();) {
+        const size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n == raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        off += n;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<unsigned char> png = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A}, ihdr;
+    be32(ihdr, w); be32(ihdr, h);
+    ihdr.push_back(8); ihdr.push_back(channels == 3 ? 2 : 0); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+    chunk(png, "IHDR", ihdr);
+    chunk(png, "IDAT", z);
+    chunk(png, "IEND", {});
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(png.data(), 1, png.size(), f) == png.size();
+    fclose(f);
+    return ok;
+}
+bool write_npy(const std::string& path, const float* data, int c, int h, int w) {
+    char dict[128];
+    snprintf(dict, sizeof(dict), "{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d, %d), }", c, h, w);
+    std::string hdr(dict);
+    while ((10 + hdr.size() + 1) % 64) hdr.push_back(' ');
+    hdr.push_back('\n');
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+    const uint16_t hl = (uint16_t)hdr.size();
+    fwrite(magic, 1, 8, f); fwrite(&hl, 2, 1, f); fwrite(hdr.data(), 1, hdr.size(), f);
+    const bool ok = fwrite(data, 4, (size_t)c * h * w, f) == (size_t)c * h * w;
+    fclose(f);
+    return ok;
+}
+unsigned char q8(float v, float scale) {
+    const float x = v * scale;
+    return (unsigned char)(x <= 0.0f ? 0 : (x >= 255.0f ? 255 : (int)x));
+}
+// planes [nplanes][rows][stride] -> interleaved 8-bit image of the top-left w x h window
+std::vector<unsigned char> to_image(const float* base, size_t plane, int stride, int w, int h, int nplanes, float scale) {
+    std::vector<unsigned char> img((size_t)w * h * nplanes);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < nplanes; c++) img[((size_t)y * w + x) * nplanes + c] = q8(base[c * plane + (size_t)y * stride + x], scale);
+    return img;
+}
+
+int die(aipt_ctx* ctx, const char* what, int rc) {
+    fprintf(stderr, "aiptd: %s failed (%d): %s\n", what, rc, aipt_last_error(ctx));
+    return 1;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
+               " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3]"
+               " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--dump-weights FILE]\n", argv[0]);
+        return 1;
+    }
+    std::string scene_path = argv[1], out_dir, weights_path, dump_weights;
+    int frames = 1, res_w = 0, res_h = 0, depth = 0, device = 0, impl = AIPT_DN_IMPL_MFMA_F16X3;
+    uint64_t wseed = 565;
+    bool npy = false;
+    uint32_t dn_flags = AIPT_DN_BN_BATCH | AIPT_DN_HIDDEN_CARRY, tr_flags = AIPT_TRACE_DEFAULT;
+    float pan = 0.35f;
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "aiptd: %s needs %d value(s)\n", a.c_str(), n); exit(1); } };
+        if (a == "--frames") { need(1); frames = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); out_dir = argv[++i]; }
+        else if (a == "--npy") npy = true;
+        else if (a == "--res") { need(2); res_w = atoi(argv[++i]); res_h = atoi(argv[++i]); }
+        else if (a == "--depth") { need(1); depth = atoi(argv[++i]); }
+        else if (a == "--weights") { need(1); weights_path = argv[++i]; }
+        else if (a == "--synthetic-weights") { need(1); wseed = strtoull(argv[++i], nullptr, 10); }
+        else if (a == "--dump-weights") { need(1); dump_weights = argv[++i]; }
+        else if (a == "--bn") { need(1); const std::string v = argv[++i]; dn_flags = (dn_flags & ~1u) | (v == "batch" ? AIPT_DN_BN_BATCH : AIPT_DN_BN_RUNNING); }
+        else if (a == "--hidden") { need(1); const std::string v = argv[++i]; dn_flags = (dn_flags & ~2u) | (v == "carry" ? AIPT_DN_HIDDEN_CARRY : AIPT_DN_HIDDEN_RESET); }
+        else if (a == "--impl") { need(1); impl = std::string(argv[++i]) == "f32" ? AIPT_DN_IMPL_MFMA : AIPT_DN_IMPL_MFMA_F16X3; }
+        else if (a == "--pan") { need(1); pan = (float)atof(argv[++i]); }
+        else if (a == "--device") { need(1); device = atoi(argv[++i]); }
+        else if (a == "--no-aa") tr_flags &= ~AIPT_TRACE_AA;
+        else if (a == "--no-compaction") tr_flags &= ~AIPT_TRACE_COMPACT;
+        else { fprintf(stderr, "aiptd: unknown option %s\n", a.c_str()); return 1; }
+    }
+    crc_init();
+
+    std::vector<unsigned char> blob;
+    if (!weights_path.empty()) {
+        FILE* f = fopen(weights_path.c_str(), "rb");
+        if (!f) { fprintf(stderr, "aiptd: cannot open %s\n", weights_path.c_str()); return 1; }
+        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+        blob.resize(n);
+        if (fread(blob.data(), 1, n, f) != (size_t)n) { fclose(f); return 1; }
+        fclose(f);
+    } else {
+        blob = make_synth_blob(wseed);          // the reference ships no trained weights
+    }
+    if (!dump_weights.empty()) {
+        FILE* f = fopen(dump_weights.c_str(), "wb");
+        if (!f || fwrite(blob.data(), 1, blob.size(), f) != blob.size()) { fprintf(stderr, "aiptd: cannot write %s\n", dump_weights.c_str()); return 1; }
+        fclose(f);
+        if (frames <= 0) return 0;
+    }
+
+    aipt_scene* scene = nullptr;
+    char err[512];
+    int rc = aipt_scene_load(scene_path.c_str(), &scene, err, sizeof(err));
+    if (rc) { fprintf(stderr, "aiptd: %s\n", err); return 1; }
+    if (res_w > 0 && res_h > 0) aipt_scene_set_resolution(scene, res_w, res_h);
+    int ngeoms, nmats, nfaces, iterations, scene_depth;
+    aipt_scene_info(scene, &ngeoms, &nmats, &nfaces, &iterations, &scene_depth);
+    if (depth <= 0) depth = scene_depth;
+    aipt_camera cam0;
+    aipt_scene_camera(scene, &cam0);
+    float zoom, phi0, theta;
+    aipt_scene_orbit_params(scene, &zoom, &phi0, &theta);
+    const int W = cam0.resolution[0], H = cam0.resolution[1];
+    printf("aiptd: %s: %d primitives, %d materials, %d faces; %dx%d depth %d; %d frame(s)\n", scene_path.c_str(), ngeoms,
+           nmats, nfaces, W, H, depth, frames);
+
+    aipt_ctx* ctx = nullptr;
+    rc = aipt_create(device, nullptr, &ctx);
+    if (rc) { fprintf(stderr, "aiptd: %s\n", aipt_last_error(nullptr)); return 1; }
+    if ((rc = aipt_scene_upload_host(ctx, scene))) return die(ctx, "aipt_scene_upload_host", rc);
+    if ((rc = aipt_denoise_load_weights(ctx, blob.data(), blob.size()))) return die(ctx, "aipt_denoise_load_weights", rc);
+    if ((rc = aipt_frame_configure(ctx, W, H))) return die(ctx, "aipt_frame_configure", rc);
+    if ((rc = aipt_denoise_set_impl(ctx, impl))) return die(ctx, "aipt_denoise_set_impl", rc);
+    float* d_out = nullptr;
+    if ((rc = aipt_malloc(ctx, sizeof(float) * 3 * W * H, (void**)&d_out))) return die(ctx, "aipt_malloc", rc);
+    float* d_gbuf; int rows, stride;
+    aipt_gbuffer(ctx, &d_gbuf, &rows, &stride);
+    const size_t plane = (size_t)rows * stride;
+    std::vector<float> h_g(10 * plane), h_o((size_t)3 * W * H);
+    const bool save = !out_dir.empty();
+    if (save) {
+        mkdir(out_dir.c_str(), 0755);
+        for (const char* d : {"RGB", "Normals", "Depth", "Albedos", "Denoised"}) mkdir((out_dir + "/" + d).c_str(), 0755);
+    }
+    aipt_frame_set_timing(ctx, 1);
+    double sum_t = 0, sum_d = 0;
+    aipt_timer_start(ctx);
+    for (int k = 0; k < frames; k++) {
+        aipt_camera cam = cam0;
+        const float phi = phi0 + pan * std::sin(2.0 * 3.14159265358979323846 * k / 300.0);   // build-defined pan
+        aipt_camera_orbit(&cam, zoom, phi, theta);
+        uint32_t f = dn_flags;
+        if (k == 0) f &= ~AIPT_DN_HIDDEN_CARRY;
+        if ((rc = aipt_frame(ctx, &cam, 1, depth, tr_flags, f, d_out))) return die(ctx, "aipt_frame", rc);
+        if (save) {
+            float tms, dms;
+            aipt_frame_last_times(ctx, &tms, &dms);
+            sum_t += tms; sum_d += dms;
+            aipt_download(ctx, h_g.data(), d_gbuf, sizeof(float) * h_g.size());
+            aipt_download(ctx, h_o.data(), d_out, sizeof(float) * h_o.size());
+            char name[64];
+            snprintf(name, sizeof(name), "/frame_%04d", k);
+            const auto rgb = to_image(h_g.data(), plane, stride, W, H, 3, 255.0f);
+            const auto nrm = to_image(h_g.data() + 3 * plane, plane, stride, W, H, 3, 100.0f);
+            const auto dep = to_image(h_g.data() + 6 * plane, plane, stride, W, H, 1, 10.0f);
+            const auto alb = to_image(h_g.data() + 7 * plane, plane, stride, W, H, 3, 255.0f);
+            const auto den = to_image(h_o.data(), (size_t)W * H, W, W, H, 3, 255.0f);
+            bool ok = write_png(out_dir + "/RGB" + name + ".png", rgb.data(), W, H, 3) &&
+                      write_png(out_dir + "/Normals" + name + ".png", nrm.data(), W, H, 3) &&
+                      write_png(out_dir + "/Depth" + name + ".png", dep.data(), W, H, 1) &&
+                      write_png(out_dir + "/Albedos" + name + ".png", alb.data(), W, H, 3) &&
+                      write_png(out_dir + "/Denoised" + name + ".png", den.data(), W, H, 3);
+            if (npy) {
+                // the G-buffer with its padding stripped: [10][H][W]
+                std::vector<float> g((size_t)10 * W * H);
+                for (int c = 0; c < 10; c++)
+                    for (int y = 0; y < H; y++)
+                        memcpy(&g[((size_t)c * H + y) * W], &h_g[c * plane + (size_t)y * stride], sizeof(float) * W);
+                ok = ok && write_npy(out_dir + name + "_gbuffer.npy", g.data(), 10, H, W) &&
+                     write_npy(out_dir + name + "_denoised.npy", h_o.data(), 3, H, W);
+            }
+            if (!ok) { fprintf(stderr, "aiptd: cannot write frame %d under %s\n", k, out_dir.c_str()); return 1; }
+        }
+    }
+    float total_ms = 0;
+    aipt_timer_stop(ctx, &total_ms);
+    if (!save) {
+        float tms, dms;
+        aipt_frame_last_times(ctx, &tms, &dms);
+        sum_t = tms * frames; sum_d = dms * frames;
+    }
+    printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"depth\": %d, \"frames_per_s\": %.3f, \"ms_trace\": %.4f, "
+           "\"ms_denoise\": %.4f, \"includes_file_output\": %s}\n", frames, W, H, depth, frames / (total_ms * 1e-3),
+           sum_t / frames, sum_d / frames, save ? "true" : "false");
+    aipt_free(ctx, d_out);
+    aipt_destroy(ctx);
+    aipt_scene_release(scene);
+    return 0;
+}

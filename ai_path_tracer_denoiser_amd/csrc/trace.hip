@@ -51,6 +51,7 @@ struct TraceState {
     int* d_cnt[2] = {nullptr, nullptr};   // per-workgroup live counts, ping-pong between bounces
     int* d_nlive = nullptr;       // [MAX_DEPTH+1]
     int* d_mat0 = nullptr;        // [P]
+    float* d_image = nullptr;     // [3][P] radiance accumulated over iterations 1..n (dev_image, pathtrace.cu:101), h-flipped
     int last_depth = 0;
     bool mat0_valid = false;
 };
@@ -72,6 +73,7 @@ struct TraceParams {
     const int* cnt_in; int* cnt_out;
     int* n_live;
     int* mat0;
+    float* image;
 };
 
 // ---------------------------------------------------------------------------------------------- vector helpers
@@ -473,12 +475,17 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             if (p.mat0) p.mat0[i] = materialid;
         }
         if (new_rem == 0) {
-            // finalGather + copy_data (:393-402, :81-94) at iter 1: image == this path's colour
+            // finalGather + copy_data (:393-402, :81-94): image += colour; planes 0-2 = image / iter.  At iter 1 the image
+            // starts from zero (pathtraceInit memsets it, :102), so it is just this path's colour.
             const float fiter = (float)p.iter;
             float* gb = p.gbuf + gd;
-            gb[0] = col.x / fiter;
-            gb[p.plane] = col.y / fiter;
-            gb[p.plane * 2] = col.z / fiter;
+            const size_t ii = (size_t)y * p.W + (size_t)(p.W - x - 1);
+            float ax = col.x, ay = col.y, az = col.z;
+            if (p.iter > 1) { ax = p.image[ii] + col.x; ay = p.image[ii + P] + col.y; az = p.image[ii + 2 * (size_t)P] + col.z; }
+            p.image[ii] = ax; p.image[ii + P] = ay; p.image[ii + 2 * (size_t)P] = az;
+            gb[0] = ax / fiter;
+            gb[p.plane] = ay / fiter;
+            gb[p.plane * 2] = az / fiter;
             remp[i] = 0;
         } else {
             ox[i] = o.x; oy[i] = o.y; oz[i] = o.z;
@@ -504,7 +511,7 @@ void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
     hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
-    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0);
+    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
     delete s;
     ctx->trace = nullptr;
 }
@@ -590,14 +597,15 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     TraceState* s = tstate(ctx);
     if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
-    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0);
-    s->d_state = nullptr; s->d_cnt[0] = s->d_cnt[1] = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr;
+    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
+    s->d_state = nullptr; s->d_cnt[0] = s->d_cnt[1] = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
     const int P = width * height, nblk = (P + 255) / 256;
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float) * 10 * (size_t)P));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt[0], sizeof(int) * nblk));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt[1], sizeof(int) * nblk));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * (size_t)P));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * (size_t)P));
     s->W = width; s->H = height; s->P = P; s->nblk = nblk;
     s->mat0_valid = false;
     return AIPT_OK;
@@ -614,7 +622,7 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
         return fail(ctx, AIPT_E_INVALID, "aipt_trace: camera is %dx%d, configured %dx%d", cam->resolution[0],
                     cam->resolution[1], s->W, s->H);
     if (depth < 1 || depth > MAX_DEPTH) return fail(ctx, AIPT_E_INVALID, "aipt_trace: depth %d not in 1..%d", depth, MAX_DEPTH);
-    if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace: only the 1-spp iteration (iter == 1) is implemented");
+    if (iter < 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace: iter %d (iterations count from 1, main.cpp:149)", iter);
     if (gbuf_rows < s->H || gbuf_stride < s->W) return fail(ctx, AIPT_E_INVALID, "aipt_trace: G-buffer %dx%d too small", gbuf_rows, gbuf_stride);
     TraceParams p;
     p.cam = *cam; p.iter = iter; p.trace_depth = depth; p.flags = flags;
@@ -626,6 +634,7 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     p.gbuf = d_gbuf; p.plane = (size_t)gbuf_rows * gbuf_stride; p.stride = gbuf_stride;
     p.n_live = s->d_nlive;
     p.mat0 = (flags & AIPT_TRACE_RECORD_MAT0) ? s->d_mat0 : nullptr;
+    p.image = s->d_image;
     AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), ctx->stream));
     for (int b = 0; b < depth; b++) {
         p.bounce = b;

@@ -130,7 +130,9 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
 int aipt_scene_free(aipt_ctx* ctx);                      /* pathtraceFree (pathtrace.cu:131-145) */
 /* pathtraceInit, frame-size part: path-state buffers for width x height pixels (allocated once, not per frame). */
 int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
-/* pathtrace (pathtrace.cu:422-528), one 1-spp iteration.  d_gbuf is float[10][gbuf_rows][gbuf_stride] with
+/* pathtrace (pathtrace.cu:422-528), one iteration.  iter = 1 starts a new image (the interactive loop always does,
+ * main.cpp:122-124,164); iter = 2, 3, ... with the same camera accumulate further samples into the context's image, planes
+ * 0-2 become image / iter (multi-spp / ground-truth mode, main.cpp:147-151); planes 3-9 are written at iter == 1 only.  d_gbuf is float[10][gbuf_rows][gbuf_stride] with
  * gbuf_rows >= height and gbuf_stride >= width; the 10 planes are: 0-2 radiance/iter, 3-5 first-hit normal, 6 first-hit
  * distance, 7-9 first-bounce albedo, horizontally flipped exactly as copy_data / computeIntersections write them
  * (pathtrace.cu:81-94, 295-304, 379-387).  Every in-frame element is written each call; padding is left untouched. */

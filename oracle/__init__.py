@@ -155,6 +155,8 @@ def _trace_lib():
         L.orc_pathtrace.restype = C.c_int
         L.orc_pathtrace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_pathtrace_accum.restype = C.c_int
+        L.orc_pathtrace_accum.argtypes = L.orc_pathtrace.argtypes + [C.c_void_p]
         L.orc_build_geom.argtypes = [C.c_void_p]
         L.orc_camera_setup.argtypes = [C.c_void_p, C.c_float]
         L.orc_camera_orbit_params.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
@@ -291,17 +293,19 @@ class OracleScene:
             fa = (Face * max(1, len(self.faces)))(*self.faces)
         return ga, ma, fa
 
-    def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True):
+    def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True, accum=None, gbuf=None):
         """One 1-spp frame (pathtrace.cu:422-528).  Returns (gbuf[10,Hp,W], n_live[depth+1], mat0[H*W])."""
         L = _trace_lib()
         W, H = self.camera.res[0], self.camera.res[1]
         Hp = pad_rows_to or H
         depth = depth or self.depth
-        gbuf = np.zeros((10, Hp, W), np.float32)
+        if gbuf is None:
+            gbuf = np.zeros((10, Hp, W), np.float32)
         n_live = np.full(depth + 1, -1, np.int32)
         mat0 = np.full(W * H, -2, np.int32)
         ga, ma, fa = self.arrays()
-        nb = L.orc_pathtrace(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
-                             self.nfaces, C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
-                             n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None)
+        nb = L.orc_pathtrace_accum(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
+                                   self.nfaces, C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
+                                   n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None,
+                                   accum.ctypes.data if accum is not None else None)
         return gbuf, n_live[:nb + 1], mat0

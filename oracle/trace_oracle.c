@@ -440,16 +440,30 @@ float orc_intersect_scene(const float* ro, const float* rd, const orc_geom* geom
  *   mat0       : optional int[W*H] first-hit material id per pixel index (-1 = miss) -- integer parity channel.
  * Returns the number of bounces executed.
  */
+int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
+                        const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth,
+                        float* gbuf, int Hp, int* n_live, int* mat0, float* accum);
+
 int orc_pathtrace(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
                   const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth,
                   float* gbuf, int Hp, int* n_live, int* mat0) {
+    return orc_pathtrace_accum(cam, geoms, ngeoms, mats, nmats, faces, nfaces, box, iter, traceDepth, gbuf, Hp, n_live,
+                               mat0, NULL);
+}
+
+/* accum: optional float[3*W*H] = the reference's dev_image (glm::vec3 per pixel, pathtrace.cu:101-102), kept by the caller
+ * across iterations 1..n of a multi-sample render (image += colour each iteration, planes 0-2 = image / iter,
+ * pathtrace.cu:400, 88-92); planes 3-9 are only written at iter == 1 (:295, :379). */
+int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
+                        const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth,
+                        float* gbuf, int Hp, int* n_live, int* mat0, float* accum) {
     const int W = cam->res[0], H = cam->res[1];
     const int P = W * H;
     const size_t plane = (size_t)W * Hp;
     path_t* paths = (path_t*)malloc(sizeof(path_t) * P);
     path_t* tmp = (path_t*)malloc(sizeof(path_t) * P);
     hit_t* hits = (hit_t*)malloc(sizeof(hit_t) * P);
-    v3* image = (v3*)calloc(P, sizeof(v3));
+    v3* image = accum ? (v3*)accum : (v3*)calloc(P, sizeof(v3));
     (void)nmats;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < P; i++) generateRay(cam, iter, traceDepth, i % W, i / W, &paths[i]);
@@ -528,7 +542,8 @@ int orc_pathtrace(const orc_camera* cam, const orc_geom* geoms, int ngeoms, cons
             gbuf[plane + d] = pix.y / fiter;
             gbuf[plane * 2 + d] = pix.z / fiter;
         }
-    free(paths); free(tmp); free(hits); free(image);
+    free(paths); free(tmp); free(hits);
+    if (!accum) free(image);
     return depth;
 }
 

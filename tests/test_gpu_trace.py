@@ -90,3 +90,24 @@ def test_errors_are_reported(ctx):
     bad[0].materialid = 99
     with pytest.raises(api.AiptError):
         ctx.pathtrace_init(bad, mats)
+
+
+def test_multi_spp_accumulation(ctx):
+    """iter = 1..4 with a fixed camera: image += colour per iteration, planes 0-2 = image / iter (pathtrace.cu:400, 88-92)."""
+    import torch
+    import oracle
+    from tests.gpu_util import to_api_scene
+    W, H, depth = 96, 64, 4
+    sc = oracle.OracleScene.parse(CORNELL, res=(W, H), depth=depth)
+    geoms, mats, faces, box, cam = to_api_scene(sc)
+    ctx.pathtrace_init(geoms, mats, faces, box, W, H)
+    gbuf = torch.zeros(10, H, W, device="cuda")
+    accum = np.zeros(3 * W * H, np.float32)
+    g_ref = np.zeros((10, H, W), np.float32)
+    for it in range(1, 5):
+        ctx.pathtrace(cam, it, depth, gbuf)
+        ctx.sync()
+        sc.pathtrace(iter=it, accum=accum, gbuf=g_ref)
+        assert np.array_equal(gbuf.cpu().numpy(), g_ref), f"iteration {it}"
+    one, _, _ = sc.pathtrace(iter=1)
+    assert not np.array_equal(one[0:3], g_ref[0:3]) and np.array_equal(one[3:10], g_ref[3:10])

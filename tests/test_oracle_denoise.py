@@ -67,3 +67,14 @@ def test_blob_roundtrip_and_param_count():
         for f in p[k]:
             assert np.array_equal(p[k][f], q[k][f])
     assert abs(arch.conv_flops(736, 1280) / 1e9 - 139.87) < 0.01
+
+
+def test_state_dict_exporter_roundtrip():
+    """Weight interchange: the reference's {'net': state_dict} key names (Appendix A.3) -> flat blob."""
+    import torch
+    p = synth.make_params(9)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in arch.state_dict_from_params(p).items()}
+    sd["encoder1.0.layer1.1.num_batches_tracked"] = torch.tensor(3)        # extra BN buffers are ignored
+    assert arch.blob_from_state_dict(sd) == arch.pack_blob(p)
+    names = [t[1] for t in arch.layer_table()]
+    assert names[0] == "encoder1.0.layer1.0" and names[4] == "encoder2.0.layer2.0" and names[-1] == "decoder1.layer1.4"

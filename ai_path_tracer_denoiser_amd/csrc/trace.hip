@@ -49,6 +49,7 @@ struct TraceState {
     int W = 0, H = 0, P = 0, nblk = 0;
     float* d_state = nullptr;     // [10][P]: ox oy oz dx dy dz cr cg cb rem(int bits)
     int* d_cnt[2] = {nullptr, nullptr};   // per-workgroup live counts, ping-pong between bounces
+    int* d_live[2] = {nullptr, nullptr};  // live-path index lists, ping-pong between bounces
     int* d_nlive = nullptr;       // [MAX_DEPTH+1]
     int* d_mat0 = nullptr;        // [P]
     float* d_image = nullptr;     // [3][P] radiance accumulated over iterations 1..n (dev_image, pathtrace.cu:101), h-flipped
@@ -74,6 +75,8 @@ struct TraceParams {
     int* n_live;
     int* mat0;
     float* image;
+    const int* live_in;          // pixel indices of the live paths entering this bounce, in pixel order (nullptr: all pixels)
+    int* live_out;
 };
 
 // ---------------------------------------------------------------------------------------------- vector helpers
@@ -320,45 +323,32 @@ __device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hi
 template <bool FIRST>
 __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     __shared__ int s_wave[4];
-    __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * 256 + tid;
     const int P = p.P;
     float* ox = p.st;            float* oy = p.st + (size_t)P;      float* oz = p.st + (size_t)2 * P;
     float* dx = p.st + (size_t)3 * P; float* dy = p.st + (size_t)4 * P; float* dz = p.st + (size_t)5 * P;
     float* cr = p.st + (size_t)6 * P; float* cg = p.st + (size_t)7 * P; float* cb = p.st + (size_t)8 * P;
     int* remp = reinterpret_cast<int*>(p.st + (size_t)9 * P);
 
-    int rem = 0;
-    if (i < P) rem = FIRST ? p.trace_depth : remp[i];
-    const bool alive = i < P && rem != 0;
-
-    // ---- rank among live paths (the index thrust::partition would have left this path at)
-    int idx = i;
-    if (!FIRST) {
-        if (p.cnt_in[blockIdx.x] == 0) {           // nothing alive in this workgroup
+    // ---- which path does this thread advance, and at which index would thrust::partition have left it?
+    // Bounce 0: thread t = pixel t.  Later bounces walk the LIVE LIST written by trace_compact: entry t is the pixel of the
+    // t-th live path in pixel order, so t is exactly the compacted array index that seeds the RNG (pathtrace.cu:351) --
+    // every wave is full of live paths and the state planes are gathered/scattered through the (monotonic) pixel index.
+    int i, idx, rem = 0;
+    bool alive;
+    const int t = blockIdx.x * 256 + tid;
+    if (FIRST) {
+        i = t; idx = t; alive = t < P; rem = p.trace_depth;
+    } else {
+        const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
+        if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
             if (tid == 0) p.cnt_out[blockIdx.x] = 0;
             return;
         }
-        if (p.flags & AIPT_TRACE_COMPACT) {
-            int part = 0;
-            for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt_in[j];
-            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-            if (lane == 0) s_wave[wave] = part;
-            __syncthreads();
-            if (tid == 0) s_base = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
-            __syncthreads();
-            const int base = s_base;
-            const unsigned long long mask = __ballot(alive);
-            const int wrank = __popcll(mask & ((1ull << lane) - 1ull));
-            __syncthreads();
-            if (lane == 0) s_wave[wave] = __popcll(mask);
-            __syncthreads();
-            int woff = 0;
-            for (int w = 0; w < wave; w++) woff += s_wave[w];
-            idx = base + woff + wrank;
-            __syncthreads();
-        }
+        alive = t < n;
+        i = alive ? p.live_in[t] : 0;
+        idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
+        if (alive) rem = remp[i];
     }
 
     bool alive_after = false;
@@ -507,11 +497,45 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     }
 }
 
+// Stable stream compaction of the live list (the wave64 ballot/popcount analogue of thrust::partition, pathtrace.cu:505):
+// entry t of the input list survives iff its path still has bounces left; survivors keep their order.  Output position =
+// (live counts of the lower workgroups, written by trace_bounce) + (ballot prefix inside the workgroup).
+__global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.bounce == 0 ? p.P : p.n_live[p.bounce];
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int t = blockIdx.x * 256 + tid;
+    const int* remp = reinterpret_cast<const int*>(p.st + (size_t)9 * p.P);
+    int i = 0;
+    bool alive = false;
+    if (t < n) {
+        i = p.live_in ? p.live_in[t] : t;
+        alive = remp[i] != 0;
+    }
+    int part = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt_out[j];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const unsigned long long mask = __ballot(alive);
+    if (lane == 0) s_wave[wave] = part;
+    __syncthreads();
+    if (tid == 0) s_base = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
+    __syncthreads();
+    const int base = s_base;
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = __popcll(mask);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; w++) woff += s_wave[w];
+    if (alive) p.live_out[base + woff + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+}
+
 void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
     hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
-    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
+    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image); hipFree(s->d_live[0]); hipFree(s->d_live[1]);
     delete s;
     ctx->trace = nullptr;
 }
@@ -598,6 +622,8 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     TraceState* s = tstate(ctx);
     if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
     hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
+    hipFree(s->d_live[0]); hipFree(s->d_live[1]);
+    s->d_live[0] = s->d_live[1] = nullptr;
     s->d_state = nullptr; s->d_cnt[0] = s->d_cnt[1] = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
     const int P = width * height, nblk = (P + 255) / 256;
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float) * 10 * (size_t)P));
@@ -606,6 +632,8 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * (size_t)P));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * (size_t)P));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[0], sizeof(int) * (size_t)P));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[1], sizeof(int) * (size_t)P));
     s->W = width; s->H = height; s->P = P; s->nblk = nblk;
     s->mat0_valid = false;
     return AIPT_OK;
@@ -638,10 +666,13 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), ctx->stream));
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
-        p.cnt_in = s->d_cnt[b & 1];
-        p.cnt_out = s->d_cnt[(b + 1) & 1];
+        p.cnt_in = nullptr;
+        p.cnt_out = s->d_cnt[0];
+        p.live_in = b == 0 ? nullptr : s->d_live[b & 1];
+        p.live_out = s->d_live[(b + 1) & 1];
         if (b == 0) hipLaunchKernelGGL(trace_bounce<true>, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
         else hipLaunchKernelGGL(trace_bounce<false>, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
+        if (b + 1 < depth) hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
     }
     AIPT_HIP(ctx, hipGetLastError());
     s->last_depth = depth;

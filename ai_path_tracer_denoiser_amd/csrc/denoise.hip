@@ -741,7 +741,7 @@ struct DenoiseState {
     float2* partial = nullptr;
     size_t partial_elems = 0;
     bool hidden_valid = false;
-    int impl = AIPT_DN_IMPL_MFMA;
+    int impl = AIPT_DN_IMPL_MFMA_F16X3;
     std::vector<void*> allocs;
     // per-layer HIP-event profiling (aipt_denoise_profile_*)
     uint32_t prof_mask = 0;
@@ -749,6 +749,13 @@ struct DenoiseState {
     std::vector<hipEvent_t> prof_ev;     // [call][layer][2]
     char kname[NLAYERS][40] = {};        // kernel that ran each layer in the last forward
 };
+
+// smallest level (in pixels) that runs on the split-fp16 kernel; below it the f32-MFMA kernels with their smaller tiles
+// fill the chip better (AIPT_F16_MINPIX overrides, for tuning)
+static long f16_min_pixels() {
+    static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
+    return v;
+}
 
 static void build_table(int* cin, int* cout) {
     int n = 0, c_in = 10;
@@ -889,7 +896,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         g.nblk = nblk;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= 200000 && H % 8 == 0) {
+    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;

@@ -18,7 +18,7 @@ def ctx():
     c.close()
 
 
-def _run_gpu(ctx, blob, frames, H, W, bn_batch, carry, impl=api.DN_IMPL_MFMA):
+def _run_gpu(ctx, blob, frames, H, W, bn_batch, carry, impl=api.DN_IMPL_MFMA_F16X3):
     import torch
     ctx.load_weights(blob)
     ctx.denoise_configure(H, W)
@@ -58,10 +58,10 @@ def test_against_reference_goldens(ctx, golden_dir, name):
 
 @pytest.mark.parametrize("bn_batch", [True, False])
 @pytest.mark.parametrize("carry", [True, False])
-@pytest.mark.parametrize("impl", [api.DN_IMPL_MFMA, api.DN_IMPL_VALU])
+@pytest.mark.parametrize("impl", [api.DN_IMPL_MFMA, api.DN_IMPL_VALU, api.DN_IMPL_MFMA_F16X3])
 def test_against_oracle_small(ctx, bn_batch, carry, impl):
     from oracle import DenoiseOracle
-    H, W = 64, 96
+    H, W = 128, 160          # level 0 (20480 px) and level 1 are big enough for the split-fp16 kernel
     blob = synth.make_blob(11)
     frames = [synth.make_gbuffer(H, W, 5, j) for j in range(2)]
     outs = _run_gpu(ctx, blob, frames, H, W, bn_batch, carry, impl)

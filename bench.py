@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 MI355X_HBM_BPS = 8.0e12          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MI355X_FP32_MFMA_TFLOPS = 157.3  # f32-input MFMA dense peak = fp32 vector peak
+MI355X_FP16_MFMA_TFLOPS = 2500.0  # fp16/bf16 dense MFMA peak (no sparsity)
 
 
 def main():
@@ -169,19 +170,45 @@ def main():
         launches = ncalls * len(prof_layers)
         tot_ms = float(sum(ms28[l] for l in prof_layers))
         flops_per_frame = sum(layer_tbl[l]["flops"] for l in prof_layers)
+
+        def layer_bytes(l):
+            # algorithmic HBM bytes of one conv launch: every input channel read once at its STORED resolution (the
+            # decoders' first convs read half-resolution sources through the fused upsample) + every output written once
+            info = layer_tbl[l]
+            src_px = info["h"] * info["w"] // 4 if (l >= 18 and (l - 18) % 2 == 0) else info["h"] * info["w"]
+            return 4.0 * (info["cin"] * src_px + info["cout"] * info["h"] * info["w"])
+        bytes_per_frame = sum(layer_bytes(l) for l in prof_layers)
         avg_ms = tot_ms / max(1, launches)
-        achieved = flops_per_frame * ncalls / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        tflops = flops_per_frame * ncalls / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        gbps = bytes_per_frame * ncalls / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        split = dominant.startswith("conv3x3_f16x3")
+        # MFMA ceiling of the kernel's arithmetic: f32-input MFMA 157.3 TFLOP/s; split-fp16 = fp16 dense peak / 3 MFMAs
+        mfma_peak = MI355X_FP16_MFMA_TFLOPS / 3.0 if split else MI355X_FP32_MFMA_TFLOPS
+        ai = flops_per_frame / bytes_per_frame
+        hbm_bound = ai < mfma_peak * 1e12 / MI355X_HBM_BPS
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_dominant.json")
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))
+                traffic = pj.get("hbm_bytes_per_launch") if pj.get("kernel") == dominant else None
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": MI355X_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MI355X_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        mfma = {"achieved_tflops_algorithmic": round(tflops, 2), "peak_tflops": round(mfma_peak, 1),
+                "frac": round(tflops / mfma_peak, 4),
+                "note": ("fp16 dense MFMA peak 2500 / 3 MFMAs per fp32-class product" if split else "f32-input MFMA peak")}
+        hbm = {"achieved_GBps_algorithmic": round(gbps, 1), "peak_GBps": MI355X_HBM_BPS / 1e9,
+               "frac": round(gbps * 1e9 / MI355X_HBM_BPS, 4)}
+        roof = {"bound": "hbm" if hbm_bound else "mfma",
+                "achieved": round(gbps, 1) if hbm_bound else round(tflops, 3),
+                "peak": MI355X_HBM_BPS / 1e9 if hbm_bound else round(mfma_peak, 1),
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": hbm["frac"] if hbm_bound else mfma["frac"],
+                "traffic": traffic,
                 "kernel": dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
+                "algorithmic_bytes_per_launch": bytes_per_frame / len(prof_layers),
                 "flops_per_launch": flops_per_frame / len(prof_layers),
+                "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma": mfma, "hbm": hbm,
                 "layers": [arch.layer_table()[l][0] for l in prof_layers]}
 
     fps = world * args.steps / elapsed
@@ -215,7 +242,8 @@ def main():
         line = {
             "metric": "denoised frames/sec @1280x720 1spp depth8", "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate)" if args.impl == "f16x3" else "f32", "data": "synthetic",
             "config": {"workload": (f"Cornell box (7 primitives, no mesh)" if not args.mesh else
                                     f"Cornell walls + procedural Sponza-like atrium mesh ({args.mesh} triangles, BVH)")
                                    + f" {W}x{H}, 1spp, depth {depth}, orbit pan, BN {args.bn}-stats, hidden {args.hidden}, "

@@ -54,7 +54,29 @@ struct ConvArgs {
     float2* partial;     // [cout][nblk]
     int nblk;
     int d2s;             // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to out[j][2y+a][2x+b]
+    int tiles_x, tiles_y, groups;   // pixel tiles and output-channel groups of the launch (1-D XCD-aware grid)
 };
+
+// 1-D grid -> (pixel tile, output-channel group), XCD-aware.  Workgroup b runs on XCD b % 8 (observed dispatch order;
+// used for speed only).  Each XCD gets a CONTIGUOUS range of pixel tiles and walks it with the channel group as the
+// fastest index, so (a) neighbouring tiles' halos and (b) the same tile's input for the next channel group are served
+// from that XCD's L2 instead of being fetched again (the per-XCD L2s are not shared).
+struct TileId { int tx, ty, gz, lin; bool valid; };
+__device__ __forceinline__ TileId tile_of_block(int tiles_x, int tiles_y, int groups) {
+    TileId t;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int ntiles = tiles_x * tiles_y, per = (ntiles + 7) >> 3;
+    t.gz = slot % groups;
+    const int tl = slot / groups;
+    t.lin = xcd * per + tl;
+    t.valid = tl < per && t.lin < ntiles;
+    t.ty = t.lin / tiles_x;
+    t.tx = t.lin - t.ty * tiles_x;
+    return t;
+}
+static inline unsigned grid_1d(int tiles_x, int tiles_y, int groups) {
+    return 8u * (unsigned)((tiles_x * tiles_y + 7) / 8) * (unsigned)groups;
+}
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
 
@@ -104,8 +126,10 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
     float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::STAGE);   // per concat channel (a, b)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const int n0 = blockIdx.z * NBB * 16;      // first output channel of this block
+    const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
+    if (!tile.valid) return;
+    const int tx0 = tile.tx * TW, ty0 = tile.ty * TH;
+    const int n0 = tile.gz * NBB * 16;         // first output channel of this block
     const int H = g.H, W = g.W;
     const int lk = lane >> 4, li = lane & 15;
     const int aC = g.a.C, ctot = g.a.C + g.b.C;
@@ -285,7 +309,7 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
             if (j < g.cout) {
                 float2 t = red[tid];
                 for (int w = 1; w < 4; w++) { t.x += red[w * (NBB * 16) + tid].x; t.y += red[w * (NBB * 16) + tid].y; }
-                g.partial[(size_t)j * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+                g.partial[(size_t)j * g.nblk + tile.lin] = t;
             }
         }
     }
@@ -319,6 +343,7 @@ struct ConvArgsH {
     int out_lrelu;
     float2* partial;
     int nblk;
+    int tiles_x, tiles_y, groups;
 };
 
 template <int RW>
@@ -345,8 +370,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx0 = blockIdx.x * 32, ty0 = blockIdx.y * TH;
-    const int n0 = blockIdx.z * 32;
+    const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
+    if (!tile.valid) return;
+    const int tx0 = tile.tx * 32, ty0 = tile.ty * TH;
+    const int n0 = tile.gz * 32;
     const int H = g.H, W = g.W;
     const int li = lane & 31, lg = lane >> 5;
     const int aC = g.a.C, ctot = g.a.C + g.b.C;
@@ -513,7 +540,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
             if (jj < g.cout) {
                 float2 t = red[tid];
                 for (int w = 1; w < 4; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
-                g.partial[(size_t)jj * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+                g.partial[(size_t)jj * g.nblk + tile.lin] = t;
             }
         }
     }
@@ -815,8 +842,9 @@ static DenoiseState* state(aipt_ctx* ctx) {
 }
 
 template <int RW, int MBX, int NBB>
-static void launch_mfma(const ConvArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv3x3_mfma<RW, MBX, NBB>), grid, dim3(256), 0, st, a);
+static void launch_mfma(ConvArgs a, dim3 grid, hipStream_t st) {
+    a.tiles_x = grid.x; a.tiles_y = grid.y; a.groups = grid.z;
+    hipLaunchKernelGGL((conv3x3_mfma<RW, MBX, NBB>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, st, a);
 }
 
 struct TileChoice { int rw, mbx, nbb; };
@@ -910,7 +938,8 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.partial = batch ? s->partial : nullptr;
         gh.nblk = nblk;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<2>");
-        hipLaunchKernelGGL((conv3x3_f16x3<2>), grid, dim3(256), 0, ctx->stream, gh);
+        gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
+        hipLaunchKernelGGL((conv3x3_f16x3<2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
         nblk = conv_nblk(t, H, W);

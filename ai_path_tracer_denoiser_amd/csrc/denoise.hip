@@ -34,13 +34,21 @@ static const int DEC_CH[6] = {0, 3, 32, 43, 57, 76};
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Activation layout in HBM: channel-QUAD interleaved, float[ceil(C/4)][h][w][4] ("C4"): one 16-byte load gives a lane the
+// four channels of a pixel -- the unit the conv kernels stage (measured 6.1 TB/s of halo fetch vs 2.9 TB/s with 4-byte
+// loads from planar tensors, tools/membench.hip).  Pad channels of the last quad hold 0.  Only the network input (the
+// G-buffer contract is planar, pathtrace.cu:81-94) and the API-facing outputs are planar.
 struct ConvSrc {
-    const float* p;      // [C][sh][sw]
+    const float* p;      // C4: [ceil(C/4)][sh][sw][4]   (planar != 0: [C][sh][sw])
     const float2* ab;    // per-channel affine, nullptr = identity
     int C;
     int up;              // 1: stored at half resolution, nearest-upsampled on load
     float slope;         // LeakyReLU slope applied after the affine (1 = none)
+    int planar;
 };
+__host__ __device__ __forceinline__ int pad4(int c) { return (c + 3) & ~3; }
+// Channel concat (a's channels first) is indexed in the PADDED-CONCAT space pc: [0, pad4(a.C)) is a, then b; weights are laid
+// out over pc with zero rows for the pad channels, so a channel quad never straddles the two sources.
 
 struct ConvArgs {
     ConvSrc a, b;        // channel concat: a's channels first
@@ -83,12 +91,51 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.0f ?
 __device__ __forceinline__ float load_src(const ConvSrc& s, int ch, int y, int x, int H, int W) {
     const int sh = s.up ? (H >> 1) : H, sw = s.up ? (W >> 1) : W;
     const int sy = s.up ? (y >> 1) : y, sx = s.up ? (x >> 1) : x;
-    float v = s.p[((size_t)ch * sh + sy) * sw + sx];
+    float v = s.planar ? s.p[((size_t)ch * sh + sy) * sw + sx]
+                       : s.p[(((size_t)(ch >> 2) * sh + sy) * sw + sx) * 4 + (ch & 3)];
     if (s.ab) {
         const float2 ab = s.ab[ch];
         v = fmaf(ab.x, v, ab.y);
     }
     return lrelu(v, s.slope);
+}
+
+// per padded-concat channel (a, b) table in LDS; pad channels and channels past the end get (0, 0) so they stage as 0
+__device__ __forceinline__ void fill_abs_tab(float2* abs_tab, const ConvSrc& a, const ConvSrc& b, int entries, int tid,
+                                             int nthreads) {
+    const int PA = pad4(a.C);
+    for (int pc = tid; pc < entries; pc += nthreads) {
+        float2 t = make_float2(0.0f, 0.0f);
+        if (pc < PA) { if (pc < a.C) t = a.ab ? a.ab[pc] : make_float2(1.0f, 0.0f); }
+        else if (pc - PA < b.C) t = b.ab ? b.ab[pc - PA] : make_float2(1.0f, 0.0f);
+        abs_tab[pc] = t;
+    }
+}
+// the four values of a (source, channel quad, pixel): one 16-byte load from a C4 tensor, four 4-byte loads from a planar one
+__device__ __forceinline__ float4 load_quad(const ConvSrc& s, int lq, size_t plane, int goff) {
+    if (!s.planar) return reinterpret_cast<const float4*>(s.p)[(size_t)lq * plane + goff];
+    float4 v;
+    const int c0 = lq * 4, cm = s.C - 1;
+    v.x = s.p[(size_t)(c0 < cm ? c0 : cm) * plane + goff];
+    v.y = s.p[(size_t)(c0 + 1 < cm ? c0 + 1 : cm) * plane + goff];
+    v.z = s.p[(size_t)(c0 + 2 < cm ? c0 + 2 : cm) * plane + goff];
+    v.w = s.p[(size_t)(c0 + 3 < cm ? c0 + 3 : cm) * plane + goff];
+    return v;
+}
+// 4x4 transpose across a quad of lanes: in: lane t holds r[i] = value(pixel i, channel t); out: r[i] = value(pixel t, channel i)
+__device__ __forceinline__ void quad_transpose(float (&r)[4], int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const float send = (lane & 1) ? r[i] : r[i + 1];
+        const float recv = __shfl_xor(send, 1);
+        if (lane & 1) r[i] = recv; else r[i + 1] = recv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float send = (lane & 2) ? r[i] : r[i + 2];
+        const float recv = __shfl_xor(send, 2);
+        if (lane & 2) r[i] = recv; else r[i + 2] = recv;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- MFMA conv
@@ -112,16 +159,16 @@ struct ConvCfg {
     static constexpr int A_FLOATS = KC * CS;
     static constexpr int B_FLOATS = 9 * KC * NPB;
     static constexpr int STAGE = A_FLOATS + B_FLOATS;               // one pipeline stage
-    static constexpr int NE = (KC * PL + 255) / 256;                // halo elements per thread
+    static constexpr int NU = (KC / 4 * PL + 255) / 256;            // (channel quad, halo pixel) units per thread
     static constexpr int NW = (9 * KC * NBB * 4 + 255) / 256;       // weight float4 per thread
-    static constexpr int MAXC = 208;                                // >= max concat channels (202), multiple of KC
+    static constexpr int MAXC = 208;                                // >= padded-concat channels (104 + 104), multiple of KC
 };
 
 template <int RW, int MBX, int NBB>
 __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >= 4) ? 3 : 4) void conv3x3_mfma(const ConvArgs g) {
     using Cfg = ConvCfg<RW, MBX, NBB>;
     constexpr int TH = Cfg::TH, TW = Cfg::TW, RS = Cfg::RS, PL = Cfg::PL, CS = Cfg::CS, NPB = Cfg::NPB;
-    constexpr int NE = Cfg::NE, NW = Cfg::NW;
+    constexpr int NU = Cfg::NU, NW = Cfg::NW;
     __shared__ __attribute__((aligned(16))) float smem[2 * Cfg::STAGE + 2 * Cfg::MAXC];
     float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::STAGE);   // per concat channel (a, b)
 
@@ -132,35 +179,31 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
     const int n0 = tile.gz * NBB * 16;         // first output channel of this block
     const int H = g.H, W = g.W;
     const int lk = lane >> 4, li = lane & 15;
-    const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    const int PA = pad4(g.a.C), pcin = PA + pad4(g.b.C);   // padded-concat channel space
     const int up = g.a.up;                     // both sources share the resampling mode (host checks)
     const int sw = up ? (W >> 1) : W;
     const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
 
-    for (int c = tid; c < ctot; c += 256) {
-        float2 t = make_float2(1.0f, 0.0f);
-        if (c < aC) { if (g.a.ab) t = g.a.ab[c]; }
-        else if (g.b.ab) t = g.b.ab[c - aC];
-        abs_tab[c] = t;
-    }
+    fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KC, tid, 256);
 
-    // ---- chunk-invariant part of this thread's staging elements.  Loads are issued UNCONDITIONALLY from clamped
-    // addresses and masked afterwards: a branch around a load makes hipcc wait vmcnt(0) per element.
-    static_assert(CS > PL, "the padding floats of channel 0 serve as the dump slot of out-of-range staging elements");
-    int e_goff[NE], e_lds[NE], e_c[NE];
+    // ---- chunk-invariant part of this thread's staging units: unit u -> (channel quad q of the chunk, halo pixel).
+    // Loads are issued UNCONDITIONALLY from clamped addresses and masked afterwards (abs_tab holds (0,0) for pad
+    // channels): a branch around a load makes hipcc wait vmcnt(0) per element.
+    static_assert(CS > PL + 3, "the padding floats of a channel serve as the dump slot of out-of-range staging units");
+    int u_goff[NU], u_lds[NU], u_q[NU];
     unsigned in_mask = 0;
 #pragma unroll
-    for (int j = 0; j < NE; j++) {
-        const int e = tid + j * 256;
-        const int c = e / PL;
-        const int rem = e - c * PL;
+    for (int j = 0; j < NU; j++) {
+        const int u = tid + j * 256;
+        const int q = u / PL;
+        const int rem = u - q * PL;
         const int yy = rem / RS, xx = rem - yy * RS;
         const int y = ty0 + yy - 1, x = tx0 + xx - 1;
-        const bool valid = e < KC * PL;
+        const bool valid = u < KC / 4 * PL;
         const bool in = valid && y >= 0 && y < H && x >= 0 && x < W;
-        e_c[j] = valid ? c : 0;
-        e_lds[j] = valid ? c * CS + yy * RS + xx : PL;
-        e_goff[j] = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
+        u_q[j] = valid ? q : 0;
+        u_lds[j] = valid ? q * 4 * CS + yy * RS + xx : PL;     // channel t of the quad at + t*CS
+        u_goff[j] = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
         in_mask |= in ? (1u << j) : 0u;
     }
 
@@ -172,15 +215,15 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
 #pragma unroll
             for (int n = 0; n < NBB; n++) acc[r][m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float pa[NE];
+    float4 pa[NU];
     f32x4 pw[NW];
     auto fetch = [&](int chunk) {
 #pragma unroll
-        for (int j = 0; j < NE; j++) {
-            int cg = chunk * KC + e_c[j];
-            cg = cg < ctot ? cg : ctot - 1;
-            const float* base = cg < aC ? g.a.p + (size_t)cg * plane : g.b.p + (size_t)(cg - aC) * plane;
-            pa[j] = base[e_goff[j]];
+        for (int j = 0; j < NU; j++) {
+            int pq = chunk * (KC / 4) + u_q[j];                 // quad index in the padded-concat space
+            pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
+            const bool from_a = pq * 4 < PA;
+            pa[j] = from_a ? load_quad(g.a, pq, plane, u_goff[j]) : load_quad(g.b, pq - PA / 4, plane, u_goff[j]);
         }
         const float* wsrc = g.w + (size_t)chunk * 9 * KC * g.NP + n0;
 #pragma unroll
@@ -193,12 +236,17 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
     };
     auto stash = [&](int chunk, float* As, float* Bs) {
 #pragma unroll
-        for (int j = 0; j < NE; j++) {
-            const int cg = chunk * KC + e_c[j];
-            const bool ok = ((in_mask >> j) & 1u) && cg < ctot;
-            const float2 t = abs_tab[cg < ctot ? cg : ctot - 1];
-            const float v = lrelu(fmaf(t.x, pa[j], t.y), cg < aC ? g.a.slope : g.b.slope);
-            As[e_lds[j]] = ok ? v : 0.0f;
+        for (int j = 0; j < NU; j++) {
+            const int pc = (chunk * (KC / 4) + u_q[j]) * 4;
+            const bool ok = (in_mask >> j) & 1u;
+            const float slope = pc < PA ? g.a.slope : g.b.slope;
+            const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float2 ab = abs_tab[pc + t];
+                const float v = lrelu(fmaf(ab.x, raw[t], ab.y), slope);
+                As[u_lds[j] + t * CS] = ok ? v : 0.0f;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NW; j++) {
@@ -247,17 +295,19 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
         __syncthreads();
     }
 
-    // ---- epilogue: bias (+LReLU), store raw output, per-channel sum / sum-of-squares partials
-    // D fragment: register q of lane l holds pixel 4*(l>>4)+q of the 16-pixel block, output channel l&15.
+    // ---- epilogue: bias (+LReLU), store raw output (C4 layout), per-channel sum / sum-of-squares partials
+    // D fragment: register q of lane l holds pixel 4*(l>>4)+q of the 16-pixel block, output channel l&15.  Lanes 4k..4k+3
+    // hold the four channels of quad k for the same four pixels: a 4x4 lane-quad transpose gives every lane the four
+    // channels of ONE pixel = one 16-byte store.
     float s1[NBB], s2[NBB];
 #pragma unroll
     for (int n = 0; n < NBB; n++) { s1[n] = 0.f; s2[n] = 0.f; }
-    const bool vec_ok = (W & 3) == 0;
 #pragma unroll
     for (int n = 0; n < NBB; n++) {
         const int j = n0 + n * 16 + li;
         const bool jok = j < g.cout;
         const float bj = g.bias[n0 + n * 16 + li];
+        const bool quad_ok = (j & ~3) < g.cout;                 // the quad holds at least one real channel
 #pragma unroll
         for (int r = 0; r < RW; r++) {
             const int y = ty0 + wave * RW + r;
@@ -269,27 +319,23 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
                 for (int q = 0; q < 4; q++) {
                     float t = acc[r][m][n][q] + bj;
                     if (g.out_lrelu) t = lrelu(t, SLOPE);
-                    v[q] = t;
+                    v[q] = jok ? t : 0.0f;                      // pad channels of the last quad are stored as 0
+                    if (jok && y < H && xb + q < W) { s1[n] += t; s2[n] += t * t; }
                 }
-                if (jok && y < H) {
-                    if (g.d2s) {
+                if (g.d2s) {
+                    if (jok && y < H) {
                         const int par = j / g.d2s, real = j - par * g.d2s;
-                        float* o = g.out + ((size_t)real * (2 * H) + 2 * y + (par >> 1)) * (2 * W) + (par & 1);
+                        float* o = g.out + (((size_t)(2 * y + (par >> 1)) * (2 * W)) + (par & 1)) * 4 + real;
 #pragma unroll
                         for (int q = 0; q < 4; q++)
-                            if (xb + q < W) { o[2 * (xb + q)] = v[q]; s1[n] += v[q]; s2[n] += v[q] * v[q]; }
-                    } else {
-                    float* o = g.out + ((size_t)j * H + y) * W + xb;
-                    if (vec_ok && xb + 3 < W) {
-                        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                        for (int q = 0; q < 4; q++) { s1[n] += v[q]; s2[n] += v[q] * v[q]; }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            if (xb + q < W) { o[q] = v[q]; s1[n] += v[q]; s2[n] += v[q] * v[q]; }
+                            if (xb + q < W) o[(size_t)2 * (xb + q) * 4] = v[q];
                     }
-                    }
+                } else {
+                    quad_transpose(v, lane);                    // now v[i] = channel (j&~3)+i of pixel xb + (lane&3)
+                    const int x = xb + (lane & 3);
+                    if (quad_ok && y < H && x < W)
+                        *reinterpret_cast<float4*>(g.out + (((size_t)(j >> 2) * H + y) * W + x) * 4) =
+                            make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
@@ -376,17 +422,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     const int n0 = tile.gz * 32;
     const int H = g.H, W = g.W;
     const int li = lane & 31, lg = lane >> 5;
-    const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    const int PA = pad4(g.a.C), pcin = PA + pad4(g.b.C);   // padded-concat channel space
     const int up = g.a.up;
     const int sw = up ? (W >> 1) : W;
     const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
 
-    for (int c = tid; c < ctot; c += 256) {
-        float2 t = make_float2(1.0f, 0.0f);
-        if (c < aC) { if (g.a.ab) t = g.a.ab[c]; }
-        else if (g.b.ab) t = g.b.ab[c - aC];
-        abs_tab[c] = t;
-    }
+    fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KH, tid, 256);
 
     // chunk-invariant staging units: unit u -> (channel quad q, halo pixel)
     int u_goff[NU], u_lds[NU], u_q[NU];
@@ -412,18 +453,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
 #pragma unroll
         for (int q = 0; q < 16; q++) { acc0[r][q] = 0.f; acc1[r][q] = 0.f; }
 
-    float pa[NU][4];
+    float4 pa[NU];
     u32x4 pw[NWP];
     auto fetch = [&](int chunk) {
 #pragma unroll
         for (int j = 0; j < NU; j++) {
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                int cg = chunk * KH + u_q[j] * 4 + t;
-                cg = cg < ctot ? cg : ctot - 1;
-                const float* base = cg < aC ? g.a.p + (size_t)cg * plane : g.b.p + (size_t)(cg - aC) * plane;
-                pa[j][t] = base[u_goff[j]];
-            }
+            int pq = chunk * (KH / 4) + u_q[j];                 // quad index in the padded-concat space
+            pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
+            const bool from_a = pq * 4 < PA;
+            pa[j] = from_a ? load_quad(g.a, pq, plane, u_goff[j]) : load_quad(g.b, pq - PA / 4, plane, u_goff[j]);
         }
 #pragma unroll
         for (int j = 0; j < NWP; j++) {
@@ -440,12 +478,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
 #pragma unroll
         for (int j = 0; j < NU; j++) {
             f16x4 hv, lv;
+            const int pc = (chunk * (KH / 4) + u_q[j]) * 4;
+            const bool ok = (in_mask >> j) & 1u;
+            const float slope = pc < PA ? g.a.slope : g.b.slope;
+            const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                const int cg = chunk * KH + u_q[j] * 4 + t;
-                const bool ok = ((in_mask >> j) & 1u) && cg < ctot;
-                const float2 ab = abs_tab[cg < ctot ? cg : ctot - 1];
-                float v = lrelu(fmaf(ab.x, pa[j][t], ab.y), cg < aC ? g.a.slope : g.b.slope);
+                const float2 ab = abs_tab[pc + t];               // (0,0) for pad channels
+                float v = lrelu(fmaf(ab.x, raw[t], ab.y), slope);
                 v = ok ? v : 0.0f;
                 const _Float16 h = (_Float16)v;
                 hv[t] = h;
@@ -498,11 +538,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     }
 
     // ---- epilogue.  D fragment (32x32): register q of lane l = pixel (q&3) + 8*(q>>2) + 4*(l>>5), channel l&31.
+    // Lanes 4k..4k+3 hold the four channels of quad k for the same four pixels; a lane-quad transpose turns that into
+    // one 16-byte C4 store per lane.
     const int j = n0 + li;
     const bool jok = j < g.cout;
+    const bool quad_ok = (j & ~3) < g.cout;
     const float bj = g.bias[j < g.coutp ? j : 0];
     float s1 = 0.f, s2 = 0.f;
-    const bool vec_ok = (W & 3) == 0;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         const int y = ty0 + wave * RW + r;
@@ -514,20 +556,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
             for (int q = 0; q < 4; q++) {
                 float t = (acc0[r][qq * 4 + q] + acc1[r][qq * 4 + q] * (1.0f / 2048.0f)) + bj;
                 if (g.out_lrelu) t = lrelu(t, SLOPE);
-                v[q] = t;
+                v[q] = jok ? t : 0.0f;
+                if (jok && y < H && xb + q < W) { s1 += t; s2 += t * t; }
             }
-            if (jok && y < H) {
-                float* o = g.out + ((size_t)j * H + y) * W + xb;
-                if (vec_ok && xb + 3 < W) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) { s1 += v[q]; s2 += v[q] * v[q]; }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (xb + q < W) { o[q] = v[q]; s1 += v[q]; s2 += v[q] * v[q]; }
-                }
-            }
+            quad_transpose(v, lane);
+            const int x = xb + (lane & 3);
+            if (quad_ok && y < H && x < W)
+                *reinterpret_cast<float4*>(g.out + (((size_t)(j >> 2) * H + y) * W + x) * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     if (g.partial) {
@@ -579,7 +614,8 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
             if (cg < ctot && sy >= 0 && sy < sh && sx >= 0 && sx < sw) {
                 const ConvSrc& src = cg < aC ? g.a : g.b;
                 const int ch = cg < aC ? cg : cg - aC;
-                v = src.p[((size_t)ch * sh + sy) * sw + sx];
+                v = src.planar ? src.p[((size_t)ch * sh + sy) * sw + sx]
+                               : src.p[(((size_t)(ch >> 2) * sh + sy) * sw + sx) * 4 + (ch & 3)];
                 if (src.ab) { const float2 ab = src.ab[ch]; v = fmaf(ab.x, v, ab.y); }
                 v = lrelu(v, src.slope);
             }
@@ -614,7 +650,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
     for (int j = 0; j < COUT; j++) {
         float t = acc[j] + g.bias[j];
         if (g.out_lrelu) t = lrelu(t, SLOPE);
-        if (ok && j < g.cout) g.out[((size_t)j * H + y) * W + x] = t;
+        if (ok && j < g.cout) g.out[(((size_t)(j >> 2) * H + y) * W + x) * 4 + (j & 3)] = t;
         s1[j] = ok ? t : 0.f; s2[j] = ok ? t * t : 0.f;
     }
     if (g.partial) {
@@ -652,14 +688,15 @@ __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
             }
     }
     if (g.out_lrelu) acc = lrelu(acc, SLOPE);
-    g.out[((size_t)j * g.H + y) * g.W + x] = acc;
+    g.out[(((size_t)(j >> 2) * g.H + y) * g.W + x) * 4 + (j & 3)] = acc;
 }
 
 // per-channel sum / sum-of-squares of a stored tensor (VALU path only): one block per channel
 __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, float2* partial) {
-    const float* p = t + (size_t)blockIdx.x * hw;
+    const int c = blockIdx.x;
+    const float* p = t + (size_t)(c >> 2) * hw * 4 + (c & 3);      // C4 layout
     double a = 0, b = 0;
-    for (size_t i = threadIdx.x; i < hw; i += 256) { const double v = p[i]; a += v; b += v * v; }
+    for (size_t i = threadIdx.x; i < hw; i += 256) { const double v = p[i * 4]; a += v; b += v * v; }
     __shared__ double sa[256], sb[256];
     sa[threadIdx.x] = a; sb[threadIdx.x] = b;
     __syncthreads();
@@ -705,32 +742,60 @@ __global__ __launch_bounds__(256) void bn_finalize(const float2* partial, int nb
 }
 
 // -------------------------------------------------------------------------------------------------- elementwise
-// out[c][y][x] = max over the 2x2 block of lrelu(a*raw+b): MaxPool2d(2) of the normalised tensor.
+// out = MaxPool2d(2) of the normalised tensor lrelu(a*raw+b); C4 in, C4 out: one thread per (channel quad, pooled pixel)
 __global__ __launch_bounds__(256) void pool2_norm(const float* raw, const float2* ab, float slope, int C, int H, int W,
                                                   float* out) {
-    const int h = H >> 1, w = W >> 1;
-    const size_t n = (size_t)C * h * w;
+    const int h = H >> 1, w = W >> 1, C4 = (C + 3) >> 2;
+    const size_t n = (size_t)C4 * h * w;
+    const float4* in4 = reinterpret_cast<const float4*>(raw);
+    float4* out4 = reinterpret_cast<float4*>(out);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int x = (int)(i % w);
         const size_t t = i / w;
-        const int y = (int)(t % h), c = (int)(t / h);
-        const float2 f = ab[c];
-        const float* p = raw + ((size_t)c * H + 2 * y) * W + 2 * x;
-        const float2 r0 = *reinterpret_cast<const float2*>(p);
-        const float2 r1 = *reinterpret_cast<const float2*>(p + W);
-        const float v0 = lrelu(fmaf(f.x, r0.x, f.y), slope), v1 = lrelu(fmaf(f.x, r0.y, f.y), slope);
-        const float v2 = lrelu(fmaf(f.x, r1.x, f.y), slope), v3 = lrelu(fmaf(f.x, r1.y, f.y), slope);
-        out[i] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+        const int y = (int)(t % h), q = (int)(t / h);
+        const float4* p = in4 + ((size_t)q * H + 2 * y) * W + 2 * x;
+        const float4 r[4] = {p[0], p[1], p[W], p[W + 1]};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = q * 4 + k;
+            float m = 0.0f;                                        // pad channels stay 0
+            if (c < C) {
+                const float2 f = ab[c];
+                const float e0 = k == 0 ? r[0].x : k == 1 ? r[0].y : k == 2 ? r[0].z : r[0].w;
+                const float e1 = k == 0 ? r[1].x : k == 1 ? r[1].y : k == 2 ? r[1].z : r[1].w;
+                const float e2 = k == 0 ? r[2].x : k == 1 ? r[2].y : k == 2 ? r[2].z : r[2].w;
+                const float e3 = k == 0 ? r[3].x : k == 1 ? r[3].y : k == 2 ? r[3].z : r[3].w;
+                m = fmaxf(fmaxf(lrelu(fmaf(f.x, e0, f.y), slope), lrelu(fmaf(f.x, e1, f.y), slope)),
+                          fmaxf(lrelu(fmaf(f.x, e2, f.y), slope), lrelu(fmaf(f.x, e3, f.y), slope)));
+            }
+            o[k] = m;
+        }
+        out4[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
-// out = lrelu(a*raw+b) (network output, hidden-state export)
+// planar out[c][i] = lrelu(a*raw+b) of a C4 tensor (network output, hidden-state export)
 __global__ __launch_bounds__(256) void apply_norm(const float* raw, const float2* ab, float slope, int C, size_t hw,
                                                   float* out) {
     const size_t n = (size_t)C * hw;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float2 f = ab[i / hw];
-        out[i] = lrelu(fmaf(f.x, raw[i], f.y), slope);
+        const int c = (int)(i / hw);
+        const size_t px = i - (size_t)c * hw;
+        const float2 f = ab[c];
+        out[i] = lrelu(fmaf(f.x, raw[((size_t)(c >> 2) * hw + px) * 4 + (c & 3)], f.y), slope);
+    }
+}
+
+// planar [C][hw] -> C4 (hidden-state import); pad channels are written as 0
+__global__ __launch_bounds__(256) void planar_to_c4(const float* in, int C, size_t hw, float* out) {
+    const size_t n = (size_t)pad4(C) * hw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i & 3);
+        const size_t t = i >> 2;
+        const size_t px = t % hw;
+        const int c = (int)(t / hw) * 4 + k;
+        out[i] = c < C ? in[(size_t)c * hw + px] : 0.0f;
     }
 }
 
@@ -742,6 +807,7 @@ __global__ void fill_ab_identity(float2* ab, int C) {
 // -------------------------------------------------------------------------------------------------- host side
 struct LayerW {
     int cin = 0, cout = 0, NB = 0, NP = 0, nchunks = 0;
+    int ca = 0, pcin = 0;   // channels of the first concat source; padded-concat channel count (pad4(ca) + pad4(cin - ca))
     float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
     float2* d_ab_running = nullptr;
     // split-fp16 copy of the weights for conv3x3_f16x3: [nchunks16][9][coutp32][16] hi and lo*2^11
@@ -752,10 +818,11 @@ struct LayerW {
 };
 
 struct Tensor {
-    float* p = nullptr;
+    float* p = nullptr;     // C4 layout unless planar
     float2* ab = nullptr;
     int C = 0;
     float slope = SLOPE;
+    int planar = 0;
 };
 
 struct DenoiseState {
@@ -877,18 +944,19 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
                     int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b) {
     const LayerW& L = s->L[li];
     ConvArgs g;
-    g.a = ConvSrc{A.p, A.ab, A.C, upA, A.slope};
-    if (B && use_b) g.b = ConvSrc{B->p, B->ab, B->C, upB, B->slope};
-    else g.b = ConvSrc{nullptr, nullptr, 0, 0, 1.0f};
+    g.a = ConvSrc{A.p, A.ab, A.C, upA, A.slope, A.planar};
+    if (B && use_b) g.b = ConvSrc{B->p, B->ab, B->C, upB, B->slope, B->planar};
+    else g.b = ConvSrc{nullptr, nullptr, 0, 0, 1.0f, 0};
     g.H = H; g.W = W;
     g.w = L.d_w; g.w_raw = L.d_w_raw; g.bias = L.d_bias;
     g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
-    g.nchunks = (g.a.C + g.b.C + KC - 1) / KC;
+    g.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KC - 1) / KC;      // padded-concat channel space
     g.out = dst.p; g.out_lrelu = out_lrelu;
     g.d2s = 0;
     if (B && use_b && upA != upB) return fail(ctx, AIPT_E_STATE, "layer %d: concat sources must share the resampling mode", li);
     const int expect = A.C + (B ? B->C : 0);
-    if (expect != L.cin) return fail(ctx, AIPT_E_STATE, "layer %d: %d input channels wired, %d expected", li, expect, L.cin);
+    if (expect != L.cin || A.C != L.ca)
+        return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
     int nblk = 1, fin_groups = 1, fin_stride = 0;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
@@ -930,7 +998,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
         gh.whi = L.d_whi; gh.wlo = L.d_wlo; gh.bias = L.d_bias32;
         gh.cout = L.cout; gh.coutp = L.coutp32;
-        gh.nchunks = (g.a.C + g.b.C + KH - 1) / KH;
+        gh.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
         nblk = grid.x * grid.y;
@@ -1003,7 +1071,15 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         LayerW& L = s->L[i];
         L.cin = cin[i]; L.cout = cout[i];
         L.NB = (L.cout + 15) / 16; L.NP = L.NB * 16;
-        L.nchunks = (L.cin + KC - 1) / KC;
+        // channels of the first concat source: l2a layers cat(out1, hidden), decoder c1 layers cat(prev, skip)
+        static const int dec_prev[5] = {101, 76, 57, 43, 32};
+        L.ca = L.cin;
+        if (i < 18 && i % 3 == 1) L.ca = L.cin / 2;
+        else if (i >= 18 && (i - 18) % 2 == 0) L.ca = dec_prev[(i - 18) / 2];
+        const int PA = pad4(L.ca);
+        L.pcin = PA + pad4(L.cin - L.ca);                       // padded-concat channel count
+        auto pc_of = [&](int c) { return c < L.ca ? c : PA + (c - L.ca); };
+        L.nchunks = (L.pcin + KC - 1) / KC;
         const float* w = q;          q += (size_t)9 * L.cin * L.cout;
         const float* b = q;          q += L.cout;
         const float* gamma = q;      q += L.cout;
@@ -1015,7 +1091,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         for (int j = 0; j < L.cout; j++)
             for (int c = 0; c < L.cin; c++)
                 for (int t = 0; t < 9; t++)
-                    wg[(((size_t)(c / KC) * 9 + t) * KC + (c % KC)) * L.NP + j] = w[((size_t)j * L.cin + c) * 9 + t];
+                    wg[(((size_t)(pc_of(c) / KC) * 9 + t) * KC + (pc_of(c) % KC)) * L.NP + j] = w[((size_t)j * L.cin + c) * 9 + t];
         std::vector<float> bp(L.NP, 0.0f);
         memcpy(bp.data(), b, 4 * L.cout);
         std::vector<float2> abr(L.cout);
@@ -1038,7 +1114,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                         for (int ky = 0; ky < 3; ky++)
                             for (int kx = 0; kx < 3; kx++) {
                                 const int dy = (a + ky + 1) / 2 - 1, dx = (bb + kx + 1) / 2 - 1;   // floor((a+ky-1)/2)
-                                wv[(((size_t)(c / KC) * 9 + (dy + 1) * 3 + (dx + 1)) * KC + (c % KC)) * vnp + v] +=
+                                wv[(((size_t)(pc_of(c) / KC) * 9 + (dy + 1) * 3 + (dx + 1)) * KC + (pc_of(c) % KC)) * vnp + v] +=
                                     w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx];
                             }
                 }
@@ -1050,7 +1126,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         }
         {   // split-fp16 weights
             L.coutp32 = (L.cout + 31) / 32 * 32;
-            L.nchunks16 = (L.cin + KH - 1) / KH;
+            L.nchunks16 = (L.pcin + KH - 1) / KH;
             const size_t nh = (size_t)L.nchunks16 * 9 * L.coutp32 * KH;
             std::vector<_Float16> wh(nh, (_Float16)0.0f), wl(nh, (_Float16)0.0f);
             for (int j = 0; j < L.cout; j++)
@@ -1058,7 +1134,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                     for (int t = 0; t < 9; t++) {
                         const float v = w[((size_t)j * L.cin + c) * 9 + t];
                         const _Float16 h = (_Float16)v;
-                        const size_t o = (((size_t)(c / KH) * 9 + t) * L.coutp32 + j) * KH + (c % KH);
+                        const size_t o = (((size_t)(pc_of(c) / KH) * 9 + t) * L.coutp32 + j) * KH + (pc_of(c) % KH);
                         wh[o] = h;
                         wl[o] = (_Float16)((v - (float)h) * 2048.0f);
                     }
@@ -1104,9 +1180,11 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         return AIPT_OK;
     };
     auto mk = [&](Tensor& t, int C, int lvl) -> int {
-        t.C = C; t.slope = SLOPE;
-        int rc = alloc(sizeof(float) * (size_t)C * (height >> lvl) * (width >> lvl), (void**)&t.p);
+        t.C = C; t.slope = SLOPE; t.planar = 0;
+        const size_t bytes = sizeof(float) * (size_t)pad4(C) * (height >> lvl) * (width >> lvl);   // C4 layout
+        int rc = alloc(bytes, (void**)&t.p);
         if (rc) return rc;
+        AIPT_HIP(ctx, hipMemsetAsync(t.p, 0, bytes, ctx->stream));   // pad channels of the last quad stay 0
         rc = alloc(sizeof(float2) * C, (void**)&t.ab);
         if (rc) return rc;
         hipLaunchKernelGGL(fill_ab_identity, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, C);
@@ -1166,7 +1244,7 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
     const int H = s->H, W = s->W;
     int li = 0, rc = 0;
     Tensor in;
-    in.p = const_cast<float*>(d_in10); in.ab = nullptr; in.C = 10; in.slope = 1.0f;
+    in.p = const_cast<float*>(d_in10); in.ab = nullptr; in.C = 10; in.slope = 1.0f; in.planar = 1;   // G-buffer contract
     const Tensor* x = &in;
     // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
     for (int i = 0; i < 5; i++) {
@@ -1176,7 +1254,7 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
         Tensor t2 = s->T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
         if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, s->Hid[i], batch, false))) return rc;
         s->Hid[i].slope = SLOPE;
-        const size_t n = (size_t)ENC_CH[i] * (h / 2) * (w / 2);
+        const size_t n = (size_t)(pad4(ENC_CH[i]) / 4) * (h / 2) * (w / 2);     // one thread per (channel quad, pooled pixel)
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(pool2_norm, dim3(grid), dim3(256), 0, ctx->stream, s->Hid[i].p, s->Hid[i].ab, SLOPE,
                            ENC_CH[i], h, w, s->P[i].p);
@@ -1298,13 +1376,17 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
         // the other levels must read as zeros: raw 0 with identity transform
         for (int l = 0; l < 6; l++) {
             Tensor& o = s->Hid[l];
-            AIPT_HIP(ctx, hipMemsetAsync(o.p, 0, sizeof(float) * o.C * (size_t)(s->H >> l) * (s->W >> l), ctx->stream));
+            AIPT_HIP(ctx, hipMemsetAsync(o.p, 0, sizeof(float) * pad4(o.C) * (size_t)(s->H >> l) * (s->W >> l), ctx->stream));
             hipLaunchKernelGGL(fill_ab_identity, dim3((o.C + 63) / 64), dim3(64), 0, ctx->stream, o.ab, o.C);
             o.slope = 1.0f;
         }
         s->hidden_valid = true;
     }
-    AIPT_HIP(ctx, hipMemcpyAsync(t.p, d_src, sizeof(float) * t.C * hw, hipMemcpyDeviceToDevice, ctx->stream));
+    {   // planar [C][h][w] from the caller -> C4
+        const size_t n = (size_t)pad4(t.C) * hw;
+        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_src, t.C, hw, t.p);
+    }
     hipLaunchKernelGGL(fill_ab_identity, dim3((t.C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, t.C);
     t.slope = 1.0f;      // already normalised: no LReLU on load
     AIPT_HIP(ctx, hipGetLastError());

@@ -581,6 +581,206 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------- persistent split-fp16 conv
+// Same arithmetic as conv3x3_f16x3, organised for the levels where one launch has thousands of tiles but few chunks:
+//   * ONE workgroup of 512 threads per CU walks the pixel tiles t = blockIdx.x, +gridDim.x, ... (blockIdx.y = output-channel
+//     group), so the per-tile prologue/epilogue and the fetch latency overlap with the neighbouring tiles' work;
+//   * the layer's split-fp16 weights for the group (all chunks) are loaded into LDS ONCE per workgroup; rows are 32 bytes
+//     with the two 16-byte halves XOR-swizzled by bit 3 of the row index (conflict-free ds_read_b128 without padding);
+//   * every wave owns one row of the 8 x 32 tile (acc = 2 x 16 VGPRs) and stages 1/8 of every halo tile: per
+//     (tile, 16-channel chunk) STEP it has two register sets of C4 float4 loads in flight (steps s+2, s+3), writes step
+//     s+1 into the other half of a 2-stage LDS ring and runs the MFMAs of step s; one barrier per step;
+//   * odd waves stage first and multiply second, even waves the other way round, so the two waves of a SIMD keep its
+//     VALU and MFMA pipes busy at the same time.
+constexpr int PXS = 32;            // bytes per pixel / per weight row in the swizzled LDS images
+__device__ __forceinline__ int swz(int row, int h) { return row * PXS + (((h ^ (row >> 3)) & 1) << 4); }
+
+struct ConvCfgP {
+    static constexpr int TH = 8, RS = 34, PL = (TH + 2) * RS;
+    static constexpr int A_HALF = PL * PXS, STAGE = 2 * A_HALF;     // Ahi | Alo
+    static constexpr int W_CHUNK = 9 * 32 * PXS;                     // hi (or lo) weights of one chunk
+    static constexpr int MAX_CHUNKS = 6;
+    static constexpr int NU = (4 * PL + 511) / 512;                  // (channel quad, halo pixel) units per thread
+    static constexpr int MAXC = 208;
+    static size_t lds_bytes(int nchunks) { return 2 * (size_t)STAGE + 2 * (size_t)nchunks * W_CHUNK + 8 * MAXC; }
+};
+
+__global__ __launch_bounds__(512, 2) void conv3x3_f16x3p(const ConvArgsH g) {
+    using Cfg = ConvCfgP;
+    constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char* Wh = dsm + 2 * Cfg::STAGE;
+    unsigned char* Wl = Wh + g.nchunks * Cfg::W_CHUNK;
+    float2* abs_tab = reinterpret_cast<float2*>(Wl + g.nchunks * Cfg::W_CHUNK);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.y * 32;
+    const int H = g.H, W = g.W;
+    const int PA = pad4(g.a.C), pcin = PA + pad4(g.b.C);
+    const int nchunks = g.nchunks;
+    const int ntiles = g.tiles_x * g.tiles_y;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * nchunks;
+    const int up = g.a.up;
+    const int sw = up ? (W >> 1) : W;
+    const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+
+    fill_abs_tab(abs_tab, g.a, g.b, nchunks * KH, tid, 512);
+    for (int p = tid; p < nchunks * 9 * 32 * 2; p += 512) {       // resident weights: 16-byte pieces
+        const int row = p >> 1, hh = p & 1;                        // row = (chunk*9 + tap)*32 + cout
+        const int ct = row >> 5, jj = row & 31;
+        const size_t src = ((size_t)ct * g.coutp + n0 + jj) * KH + hh * 8;
+        *reinterpret_cast<u32x4*>(Wh + swz(row, hh)) = *reinterpret_cast<const u32x4*>(g.whi + src);
+        *reinterpret_cast<u32x4*>(Wl + swz(row, hh)) = *reinterpret_cast<const u32x4*>(g.wlo + src);
+    }
+
+    // chunk- and tile-invariant part of this thread's staging units
+    int u_yx[NU], u_lds[NU], u_q[NU];
+#pragma unroll
+    for (int j = 0; j < NU; j++) {
+        const int u = tid + j * 512;
+        const int q = u / PL, pix = u - q * PL;
+        const int yy = pix / RS, xx = pix - yy * RS;
+        const bool valid = u < 4 * PL;
+        u_q[j] = valid ? q : 0;
+        u_yx[j] = valid ? (yy << 16) | xx : -1;
+        u_lds[j] = swz(pix, q >> 1) + (q & 1) * 8;
+    }
+    float4 pa0[NU], pa1[NU];
+    unsigned m0 = 0, m1 = 0;
+    int f_tile = blockIdx.x, f_chunk = 0, s_chunk = 0;
+    auto fetch = [&](float4 (&pa)[NU], unsigned& mask) {
+        const int ty0 = (f_tile / g.tiles_x) * TH, tx0 = (f_tile % g.tiles_x) * 32;
+        mask = 0;
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            const int y = ty0 + (u_yx[j] >> 16) - 1, x = tx0 + (u_yx[j] & 0xffff) - 1;
+            const bool in = u_yx[j] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
+            const int goff = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
+            mask |= in ? (1u << j) : 0u;
+            int pq = f_chunk * (KH / 4) + u_q[j];
+            pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
+            pa[j] = pq * 4 < PA ? load_quad(g.a, pq, plane, goff) : load_quad(g.b, pq - PA / 4, plane, goff);
+        }
+        if (++f_chunk == nchunks) { f_chunk = 0; f_tile += gridDim.x; }
+    };
+    auto stash = [&](const float4 (&pa)[NU], unsigned mask, unsigned char* st) {
+        unsigned char* Ahi = st;
+        unsigned char* Alo = st + Cfg::A_HALF;
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            const int pc = (s_chunk * (KH / 4) + u_q[j]) * 4;
+            const bool ok = (mask >> j) & 1u;
+            const float slope = pc < PA ? g.a.slope : g.b.slope;
+            const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
+            f16x4 hv, lv;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float2 ab = abs_tab[pc + t];
+                float v = lrelu(fmaf(ab.x, raw[t], ab.y), slope);
+                v = ok ? v : 0.0f;
+                const _Float16 h = (_Float16)v;
+                hv[t] = h;
+                lv[t] = (_Float16)((v - (float)h) * 2048.0f);
+            }
+            if (u_yx[j] >= 0) {
+                *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = hv;
+                *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = lv;
+            }
+        }
+        if (++s_chunk == nchunks) s_chunk = 0;
+    };
+
+    // ---- consumer state: this wave's row of the tile
+    const int li = lane & 31, lg = lane >> 5;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
+    const int j = n0 + li;
+    const bool jok = j < g.cout, quad_ok = (j & ~3) < g.cout;
+    const float bj = g.bias[j < g.coutp ? j : 0];
+    int c_tile = blockIdx.x, c_chunk = 0;
+    auto compute = [&](const unsigned char* st) {
+        const unsigned char* Ahi = st;
+        const unsigned char* Alo = st + Cfg::A_HALF;
+        const unsigned char* Bh = Wh + c_chunk * Cfg::W_CHUNK;      // chunk rows start at a multiple of 288: same swizzle phase
+        const unsigned char* Bl = Wl + c_chunk * Cfg::W_CHUNK;
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            f16x8 fah[3], fal[3];
+#pragma unroll
+            for (int hr = 0; hr < 3; hr++) {
+                const int off = swz((wave + hr) * RS + li + kx, lg);
+                fah[hr] = *reinterpret_cast<const f16x8*>(Ahi + off);
+                fal[hr] = *reinterpret_cast<const f16x8*>(Alo + off);
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {
+                const int boff = swz((ky * 3 + kx) * 32 + li, lg);
+                const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bh + boff);
+                const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bl + boff);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ky], fbh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ky], fbl, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ky], fbh, acc1, 0, 0, 0);
+            }
+        }
+        if (++c_chunk == nchunks) {
+            // tile epilogue for this wave's row: bias (+LReLU), lane-quad transpose, 16-byte C4 stores, BN partials
+            c_chunk = 0;
+            const int y = (c_tile / g.tiles_x) * TH + wave, tx0 = (c_tile % g.tiles_x) * 32;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                const int xb = tx0 + 8 * qq + 4 * lg;
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    float t = (acc0[qq * 4 + q] + acc1[qq * 4 + q] * (1.0f / 2048.0f)) + bj;
+                    if (g.out_lrelu) t = lrelu(t, SLOPE);
+                    v[q] = jok ? t : 0.0f;
+                    if (jok && y < H && xb + q < W) { s1 += t; s2 += t * t; }
+                    acc0[qq * 4 + q] = 0.f; acc1[qq * 4 + q] = 0.f;
+                }
+                quad_transpose(v, lane);
+                const int x = xb + (lane & 3);
+                if (quad_ok && y < H && x < W)
+                    *reinterpret_cast<float4*>(g.out + (((size_t)(j >> 2) * H + y) * W + x) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (g.partial) {
+                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                if (lg == 0 && jok) g.partial[(size_t)j * g.nblk + (size_t)c_tile * 8 + wave] = make_float2(s1, s2);
+            }
+            c_tile += gridDim.x;
+        }
+    };
+
+    // ---- pipeline.  Step s reads ring stage s&1; set pa0 carries even steps, pa1 odd steps.
+    if (S > 0) fetch(pa0, m0);
+    if (S > 1) fetch(pa1, m1);
+    __syncthreads();                                               // abs_tab + weights visible
+    if (S > 0) stash(pa0, m0, dsm);
+    if (S > 2) fetch(pa0, m0);
+    __syncthreads();
+    const bool stage_first = wave & 1;
+    for (int s = 0; s < S; s += 2) {
+        {   // step s from stage 0; stage step s+1 into stage 1
+            const bool more = s + 1 < S;
+            if (stage_first && more) { stash(pa1, m1, dsm + Cfg::STAGE); if (s + 3 < S) fetch(pa1, m1); }
+            compute(dsm);
+            if (!stage_first && more) { stash(pa1, m1, dsm + Cfg::STAGE); if (s + 3 < S) fetch(pa1, m1); }
+            __syncthreads();
+        }
+        if (s + 1 < S) {   // step s+1 from stage 1; stage step s+2 into stage 0
+            const bool more = s + 2 < S;
+            if (stage_first && more) { stash(pa0, m0, dsm); if (s + 4 < S) fetch(pa0, m0); }
+            compute(dsm + Cfg::STAGE);
+            if (!stage_first && more) { stash(pa0, m0, dsm); if (s + 4 < S) fetch(pa0, m0); }
+            __syncthreads();
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- few-output conv
 // dec1.c1 (64 -> 3) and dec1.c2 (3 -> 3) have too few output channels for an MFMA N dimension (3 of 16/32 columns used).
 // Direct conv on the VALU instead: one thread per output pixel, COUT accumulators, input halo tile in LDS (already
@@ -836,6 +1036,7 @@ struct DenoiseState {
     size_t partial_elems = 0;
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
+    int num_cus = 256;
     std::vector<void*> allocs;
     // per-layer HIP-event profiling (aipt_denoise_profile_*)
     uint32_t prof_mask = 0;
@@ -848,6 +1049,12 @@ struct DenoiseState {
 // fill the chip better (AIPT_F16_MINPIX overrides, for tuning)
 static long f16_min_pixels() {
     static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
+    return v;
+}
+
+// smallest level that runs on the persistent variant (needs thousands of 8 x 32 tiles to be worth one workgroup per CU)
+static long f16p_min_pixels() {
+    static const long v = getenv("AIPT_F16P_MINPIX") ? atol(getenv("AIPT_F16P_MINPIX")) : (1l << 40);   // off by default: not yet faster, see DESIGN.md
     return v;
 }
 
@@ -904,7 +1111,15 @@ void denoise_destroy(aipt_ctx* ctx) {
 }
 
 static DenoiseState* state(aipt_ctx* ctx) {
-    if (!ctx->dn) ctx->dn = new DenoiseState();
+    if (!ctx->dn) {
+        ctx->dn = new DenoiseState();
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->dn->num_cus = prop.multiProcessorCount;
+        // the persistent kernel keeps a layer's weights + a 2-stage activation ring in LDS (up to ~156 KB)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+    }
     return ctx->dn;
 }
 
@@ -992,6 +1207,26 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         g.nblk = nblk;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
+    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16p_min_pixels() && H % 8 == 0 && W % 32 == 0 &&
+               (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH <= ConvCfgP::MAX_CHUNKS) {
+        // thousands of tiles, few chunks: persistent split-fp16 kernel, weights resident in LDS
+        ConvArgsH gh;
+        gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
+        gh.whi = L.d_whi; gh.wlo = L.d_wlo; gh.bias = L.d_bias32;
+        gh.cout = L.cout; gh.coutp = L.coutp32;
+        gh.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH;
+        gh.out = dst.p; gh.out_lrelu = out_lrelu;
+        gh.tiles_x = W / 32; gh.tiles_y = H / 8; gh.groups = L.coutp32 / 32;
+        const int ntiles = gh.tiles_x * gh.tiles_y;
+        nblk = ntiles * 8;                                          // one BN partial per (tile, wave)
+        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        gh.partial = batch ? s->partial : nullptr;
+        gh.nblk = nblk;
+        int gx = s->num_cus / gh.groups;
+        if (gx < 1) gx = 1;
+        if (gx > ntiles) gx = ntiles;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3p");
+        hipLaunchKernelGGL(conv3x3_f16x3p, dim3(gx, gh.groups), dim3(512), ConvCfgP::lds_bytes(gh.nchunks), ctx->stream, gh);
     } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
@@ -1207,7 +1442,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     size_t mx = 0;
     for (int lvl = 0; lvl < 6; lvl++) {
         const int h = height >> lvl, w = width >> lvl;
-        const size_t tiles = (size_t)((w + 15) / 16) * ((h + 3) / 4);
+        const size_t tiles = (size_t)((w + 15) / 16) * ((h + 3) / 4) * 2;   // finest granularity: one partial per 32 pixels
         const int c = lvl < 5 ? ENC_CH[lvl] : 101;
         if (tiles * c > mx) mx = tiles * c;
     }

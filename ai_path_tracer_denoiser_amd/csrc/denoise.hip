@@ -4,7 +4,8 @@
 // training/recurrent_autoencoder_model.py:8-142 (28 x conv3x3+bias, 28 x BatchNorm2d, LeakyReLU(0.1), 5 x MaxPool2d(2),
 // 5 x nearest Upsample x2, skip concats, 6 recurrent hidden states).
 //
-// Data layout in HBM: every activation is planar fp32 [C][h][w] (the G-buffer contract is planar, pathtrace.cu:81-94).
+// Data layout in HBM: every activation is fp32 in the channel-quad interleaved "C4" layout [C/4][h][w][4] (see ConvSrc;
+// the planar G-buffer input is re-laid-out once per frame by planar_to_c4).
 // Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and
 // accumulates per-channel sum / sum-of-squares partials in its epilogue; a tiny finalize kernel turns them into a
 // per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a).  The CONSUMER applies x -> lrelu(a*x+b) while it
@@ -111,16 +112,14 @@ __device__ __forceinline__ void fill_abs_tab(float2* abs_tab, const ConvSrc& a, 
         abs_tab[pc] = t;
     }
 }
-// the four values of a (source, channel quad, pixel): one 16-byte load from a C4 tensor, four 4-byte loads from a planar one
-__device__ __forceinline__ float4 load_quad(const ConvSrc& s, int lq, size_t plane, int goff) {
-    if (!s.planar) return reinterpret_cast<const float4*>(s.p)[(size_t)lq * plane + goff];
-    float4 v;
-    const int c0 = lq * 4, cm = s.C - 1;
-    v.x = s.p[(size_t)(c0 < cm ? c0 : cm) * plane + goff];
-    v.y = s.p[(size_t)(c0 + 1 < cm ? c0 + 1 : cm) * plane + goff];
-    v.z = s.p[(size_t)(c0 + 2 < cm ? c0 + 2 : cm) * plane + goff];
-    v.w = s.p[(size_t)(c0 + 3 < cm ? c0 + 3 : cm) * plane + goff];
-    return v;
+// The four values of a (channel quad, pixel) unit.  C4 sources: ONE 16-byte load; the source of the quad (a or b of the
+// concat) is chosen with selects on the pointer/offset -- never a branch around the load (hipcc would wait vmcnt(0) per
+// unit).  Offsets fit 32 bits (quads x plane < 2^31).  (The planar network input is converted to C4 by planar_to_c4 first.)
+__device__ __forceinline__ float4 load_quad_c4(const float4* a4, const float4* b4, int pq, int PAq, unsigned plane, int goff) {
+    const bool fa = pq < PAq;
+    const unsigned off = (unsigned)(fa ? pq : pq - PAq) * plane + (unsigned)goff;
+    const float4* base = fa ? a4 : b4;
+    return base[off];
 }
 // 4x4 transpose across a quad of lanes: in: lane t holds r[i] = value(pixel i, channel t); out: r[i] = value(pixel t, channel i)
 __device__ __forceinline__ void quad_transpose(float (&r)[4], int lane) {
@@ -183,6 +182,8 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
     const int up = g.a.up;                     // both sources share the resampling mode (host checks)
     const int sw = up ? (W >> 1) : W;
     const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+    const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
+    const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
 
     fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KC, tid, 256);
 
@@ -222,8 +223,7 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
         for (int j = 0; j < NU; j++) {
             int pq = chunk * (KC / 4) + u_q[j];                 // quad index in the padded-concat space
             pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
-            const bool from_a = pq * 4 < PA;
-            pa[j] = from_a ? load_quad(g.a, pq, plane, u_goff[j]) : load_quad(g.b, pq - PA / 4, plane, u_goff[j]);
+            pa[j] = load_quad_c4(a4, b4, pq, PA / 4, (unsigned)plane, u_goff[j]);
         }
         const float* wsrc = g.w + (size_t)chunk * 9 * KC * g.NP + n0;
 #pragma unroll
@@ -426,6 +426,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     const int up = g.a.up;
     const int sw = up ? (W >> 1) : W;
     const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+    const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
+    const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
 
     fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KH, tid, 256);
 
@@ -460,8 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
         for (int j = 0; j < NU; j++) {
             int pq = chunk * (KH / 4) + u_q[j];                 // quad index in the padded-concat space
             pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
-            const bool from_a = pq * 4 < PA;
-            pa[j] = from_a ? load_quad(g.a, pq, plane, u_goff[j]) : load_quad(g.b, pq - PA / 4, plane, u_goff[j]);
+            pa[j] = load_quad_c4(a4, b4, pq, PA / 4, (unsigned)plane, u_goff[j]);
         }
 #pragma unroll
         for (int j = 0; j < NWP; j++) {
@@ -625,6 +626,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3p(const ConvArgsH g) {
     const int up = g.a.up;
     const int sw = up ? (W >> 1) : W;
     const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
+    const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
+    const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
 
     fill_abs_tab(abs_tab, g.a, g.b, nchunks * KH, tid, 512);
     for (int p = tid; p < nchunks * 9 * 32 * 2; p += 512) {       // resident weights: 16-byte pieces
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_f16x3p(const ConvArgsH g) {
             mask |= in ? (1u << j) : 0u;
             int pq = f_chunk * (KH / 4) + u_q[j];
             pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
-            pa[j] = pq * 4 < PA ? load_quad(g.a, pq, plane, goff) : load_quad(g.b, pq - PA / 4, plane, goff);
+            pa[j] = load_quad_c4(a4, b4, pq, PA / 4, (unsigned)plane, goff);
         }
         if (++f_chunk == nchunks) { f_chunk = 0; f_tile += gridDim.x; }
     };
@@ -1029,6 +1032,7 @@ struct DenoiseState {
     bool have_weights = false;
     LayerW L[NLAYERS];
     int H = 0, W = 0;
+    Tensor In;                     // C4 copy of the planar network input
     Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
     Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
     Tensor D1[6], D2[6];           // decoder k = 1..5
@@ -1425,7 +1429,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         hipLaunchKernelGGL(fill_ab_identity, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, C);
         return AIPT_OK;
     };
-    int rc = 0;
+    int rc = mk(s->In, 10, 0);
     for (int i = 0; i < 6 && !rc; i++) {
         const int c = i < 5 ? ENC_CH[i] : 101;
         rc = mk(s->T1[i], c, i);
@@ -1479,7 +1483,12 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
     const int H = s->H, W = s->W;
     int li = 0, rc = 0;
     Tensor in;
-    in.p = const_cast<float*>(d_in10); in.ab = nullptr; in.C = 10; in.slope = 1.0f; in.planar = 1;   // G-buffer contract
+    {   // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94): one small pass re-lays it out as C4
+        const size_t hw = (size_t)H * W, n = (size_t)pad4(10) * hw;
+        const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_in10, 10, hw, s->In.p);
+    }
+    in = s->In; in.ab = nullptr; in.C = 10; in.slope = 1.0f; in.planar = 0;
     const Tensor* x = &in;
     // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
     for (int i = 0; i < 5; i++) {

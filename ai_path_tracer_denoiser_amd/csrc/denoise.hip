@@ -392,21 +392,22 @@ struct ConvArgsH {
     int tiles_x, tiles_y, groups;
 };
 
-template <int RW>
+template <int RW, int NWV>
 struct ConvCfgH {
-    static constexpr int TH = 4 * RW, TW = 32;
+    static constexpr int TH = NWV * RW, TW = 32, NT = NWV * 64;
     static constexpr int RS = TW + 2;
     static constexpr int PL = (TH + 2) * RS;
     static constexpr int A_BYTES = PL * PXB;                 // one of hi / lo
     static constexpr int B_BYTES = 9 * 32 * PXB;             // one of hi / lo
-    static constexpr int NU = (4 * PL + 255) / 256;          // (pixel, channel-quad) staging units per thread
-    static constexpr int NWP = (9 * 32 * 2 * 2 + 255) / 256; // 16-byte weight pieces per thread (hi and lo)
+    static constexpr int NU = (4 * PL + NT - 1) / NT;          // (pixel, channel-quad) staging units per thread
+    static constexpr int NWP = (9 * 32 * 2 * 2 + NT - 1) / NT; // 16-byte weight pieces per thread (hi and lo)
     static constexpr int MAXC = 208;
 };
 
-template <int RW>
-__global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
-    using Cfg = ConvCfgH<RW>;
+template <int RW, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
+    using Cfg = ConvCfgH<RW, NWV>;
+    constexpr int NT = Cfg::NT;
     constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU, NWP = Cfg::NWP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES + 8 * Cfg::MAXC];
     unsigned char* Ahi = smem;
@@ -429,14 +430,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
     const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
     const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
 
-    fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KH, tid, 256);
+    fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KH, tid, NT);
 
     // chunk-invariant staging units: unit u -> (channel quad q, halo pixel)
     int u_goff[NU], u_lds[NU], u_q[NU];
     unsigned in_mask = 0;
 #pragma unroll
     for (int j = 0; j < NU; j++) {
-        const int u = tid + j * 256;
+        const int u = tid + j * NT;
         const int q = u / PL;
         const int pix = u - q * PL;
         const int yy = pix / RS, xx = pix - yy * RS;
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
         }
 #pragma unroll
         for (int j = 0; j < NWP; j++) {
-            int p = tid + j * 256;
+            int p = tid + j * NT;
             p = p < 9 * 32 * 4 ? p : 9 * 32 * 4 - 1;
             const int lo = p >= 9 * 32 * 2;                    // second half of the pieces = lo slab
             const int pp = lo ? p - 9 * 32 * 2 : p;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
         }
 #pragma unroll
         for (int j = 0; j < NWP; j++) {
-            const int p = tid + j * 256;
+            const int p = tid + j * NT;
             if (p < 9 * 32 * 4) {
                 const int lo = p >= 9 * 32 * 2;
                 const int pp = lo ? p - 9 * 32 * 2 : p;
@@ -567,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
         }
     }
     if (g.partial) {
-        float2* red = reinterpret_cast<float2*>(smem);         // [4 waves][32]; the last loop barrier already passed
+        float2* red = reinterpret_cast<float2*>(smem);         // [NWV waves][32]; the last loop barrier already passed
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (lg == 0) red[wave * 32 + li] = make_float2(s1, s2);
         __syncthreads();
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f16x3(const ConvArgsH g) {
             const int jj = n0 + tid;
             if (jj < g.cout) {
                 float2 t = red[tid];
-                for (int w = 1; w < 4; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
+                for (int w = 1; w < NWV; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
                 g.partial[(size_t)jj * g.nblk + tile.lin] = t;
             }
         }
@@ -1244,9 +1245,11 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
         gh.partial = batch ? s->partial : nullptr;
         gh.nblk = nblk;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<2>");
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
-        hipLaunchKernelGGL((conv3x3_f16x3<2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
+        static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
+        if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
+        else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
         nblk = conv_nblk(t, H, W);

@@ -484,15 +484,24 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             const bool ok = (in_mask >> j) & 1u;
             const float slope = pc < PA ? g.a.slope : g.b.slope;
             const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
+            float v[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const float2 ab = abs_tab[pc + t];               // (0,0) for pad channels
-                float v = lrelu(fmaf(ab.x, raw[t], ab.y), slope);
-                v = ok ? v : 0.0f;
-                const _Float16 h = (_Float16)v;
-                hv[t] = h;
-                lv[t] = (_Float16)((v - (float)h) * 2048.0f);
+                const float x = fmaf(ab.x, raw[t], ab.y);
+                const float y = fmaxf(x, x * slope);             // LeakyReLU for 0 < slope <= 1
+                v[t] = ok ? y : 0.0f;
             }
+            // hi = fp16(v) rounded toward zero (any fp16 near v works: lo carries the exact remainder, scaled by 2^11)
+            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+            const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+            const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+            const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.0f,
+                                                                                    (v[1] - (float)h01[1]) * 2048.0f));
+            const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.0f,
+                                                                                    (v[3] - (float)h23[1]) * 2048.0f));
+            hv[0] = h01[0]; hv[1] = h01[1]; hv[2] = h23[0]; hv[3] = h23[1];
+            lv[0] = l01[0]; lv[1] = l01[1]; lv[2] = l23[0]; lv[3] = l23[1];
             *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = hv;
             *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = lv;
         }

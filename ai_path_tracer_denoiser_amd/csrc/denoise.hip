@@ -366,25 +366,44 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
 // (hi = fp16(x), lo = fp16((x - hi) * 2^11)); three MFMAs per product keep hi*hi, hi*lo and lo*hi, accumulated in fp32
 // (the dropped lo*lo term is 2^-22 relative).  Measured accuracy equals the fp32 FMA chain, at 16/3 of its
 // MFMA rate.  M = 32 consecutive pixels of a row, N = 32 output channels, K = 16 input channels of one tap.
-// Block = 4 waves, tile = (4*RW) rows x 32 cols x 32 output channels (blockIdx.z = channel group of 32).
+// Block = NWV waves, tile = (NWV*RW) rows x 32 cols x 32 output channels (one channel group of 32 per workgroup).
+//
+// The kernel is VALU-bound before it is MFMA- or HBM-bound (PMC: 15 VALU instructions per MFMA in the first version), so
+// everything around the MFMAs is arranged to cost no vector ALU work:
+//   * K16-aligned concat space: source a owns chunks [0, ca16), source b chunks [ca16, ca16+cb16) -- the source of a chunk
+//     is wave-uniform, its base pointer lives in SGPRs and advances by a scalar per chunk; a thread's vector offset
+//     (pixel, quad-of-the-chunk) is computed once per tile;
+//   * staging unit = (halo pixel, channel quad): the quad of a thread is fixed (tid / (NT/4)), so its four (a,b) BN
+//     coefficients are two LDS reads per chunk, and consecutive lanes read consecutive 16-byte C4 pixels;
+//   * the LDS halo image is zeroed once per tile; out-of-image units never write (EXEC mask, no selects);
+//   * weights are pre-split and pre-tiled on the host as [group][chunk][hi|lo][tap][32 cout][16] halfs, so a chunk's slab
+//     is a linear 18 KB copy;
+//   * bias is the initial accumulator, pad output channels have zero weights and bias (no masking), and the BN partial
+//     sums skip the image-bounds test on interior tiles.
 // LDS holds activations channel-last as [pixel][16 hi halfs | pad] and [pixel][16 lo halfs | pad] (48-byte pixel stride:
-// ds_read_b128 / ds_write_b64 conflict-free) and the pre-split weight slab [tap][cout][16 | pad] hi and lo.
+// ds_read_b128 / ds_write_b64 conflict-free) and the weight slab [tap][cout][16 | pad] hi and lo.
 // Single LDS stage + register prefetch: the next chunk's global loads are in flight during the MFMAs.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KH = 16;             // input channels per chunk of the fp16 kernel
 constexpr int PXB = 48;            // bytes per pixel / per weight row in LDS (16 halfs + 8 halfs padding)
+constexpr int WSLAB = 2 * 9 * 32 * KH * 2;   // bytes of one (group, chunk) weight slab: hi and lo
+
+static inline int pad16(int c) { return (c + 15) & ~15; }
 
 struct ConvArgsH {
     ConvSrc a, b;
     int H, W;
-    const _Float16* whi;   // [nchunks][9][coutp][16]
-    const _Float16* wlo;
-    const float* bias;     // [coutp]
-    int cout, coutp, nchunks;
+    const unsigned char* wsplit;   // [group][chunk][hi|lo][9][32][16] halfs
+    const float* bias;             // [coutp], zero for pad channels
+    int cout, coutp;
+    int nchunks, ca16;             // chunks to run; chunks of source a
+    int wchunks;                   // chunks per group in wsplit
     float* out;
     int out_lrelu;
     float2* partial;
@@ -399,22 +418,47 @@ struct ConvCfgH {
     static constexpr int PL = (TH + 2) * RS;
     static constexpr int A_BYTES = PL * PXB;                 // one of hi / lo
     static constexpr int B_BYTES = 9 * 32 * PXB;             // one of hi / lo
-    static constexpr int NU = (4 * PL + NT - 1) / NT;          // (pixel, channel-quad) staging units per thread
-    static constexpr int NWP = (9 * 32 * 2 * 2 + NT - 1) / NT; // 16-byte weight pieces per thread (hi and lo)
-    static constexpr int MAXC = 208;
+    static constexpr int TPQ = NT / 4;                       // threads per channel quad
+    static constexpr int NU = (PL + TPQ - 1) / TPQ;          // halo pixels per thread
+    static constexpr int NWP = (WSLAB / 16 + NT - 1) / NT;   // 16-byte weight pieces per thread
+    static constexpr int MAXC = 224;                         // K16 concat channels (2 x pad16(101))
 };
+
+// quad-lane exchange on the VALU (DPP quad_perm), no LDS round trip
+__device__ __forceinline__ float dpp_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+// 4x4 transpose across a quad of lanes: in: lane t holds r[i] = value(pixel i, channel t); out: r[i] = value(pixel t, channel i)
+__device__ __forceinline__ void quad_transpose_dpp(float (&r)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+        const float p0 = dpp_xor1(r[i]), p1 = dpp_xor1(r[i + 1]);
+        r[i] = o1 ? p1 : r[i];
+        r[i + 1] = o1 ? r[i + 1] : p0;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const float p0 = dpp_xor2(r[i]), p1 = dpp_xor2(r[i + 2]);
+        r[i] = o2 ? p1 : r[i];
+        r[i + 2] = o2 ? r[i + 2] : p0;
+    }
+}
 
 template <int RW, int NWV>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
     using Cfg = ConvCfgH<RW, NWV>;
-    constexpr int NT = Cfg::NT;
+    constexpr int NT = Cfg::NT, TPQ = Cfg::TPQ;
     constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU, NWP = Cfg::NWP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES + 8 * Cfg::MAXC];
     unsigned char* Ahi = smem;
     unsigned char* Alo = smem + Cfg::A_BYTES;
     unsigned char* Bhi = smem + 2 * Cfg::A_BYTES;
-    unsigned char* Blo = Bhi + Cfg::B_BYTES;
-    float2* abs_tab = reinterpret_cast<float2*>(smem + 2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES);
+    float* tab_a = reinterpret_cast<float*>(smem + 2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES);   // BN scale per K16 channel
+    float* tab_b = tab_a + Cfg::MAXC;                                                       // BN shift
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
@@ -423,102 +467,105 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const int n0 = tile.gz * 32;
     const int H = g.H, W = g.W;
     const int li = lane & 31, lg = lane >> 5;
-    const int PA = pad4(g.a.C), pcin = PA + pad4(g.b.C);   // padded-concat channel space
     const int up = g.a.up;
     const int sw = up ? (W >> 1) : W;
-    const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
-    const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
-    const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
+    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;      // bytes of one channel quad
+    const int ca16 = g.ca16;
 
-    fill_abs_tab(abs_tab, g.a, g.b, g.nchunks * KH, tid, NT);
+    // BN coefficient table over the K16 concat space ((0,0) for pad channels) + zeroed halo image
+    for (int kc = tid; kc < g.nchunks * KH; kc += NT) {
+        const bool fa = kc < ca16 * KH;
+        const int c = fa ? kc : kc - ca16 * KH;
+        const ConvSrc& s = fa ? g.a : g.b;
+        float2 t = make_float2(0.0f, 0.0f);
+        if (c < s.C) t = s.ab ? s.ab[c] : make_float2(1.0f, 0.0f);
+        tab_a[kc] = t.x;
+        tab_b[kc] = t.y;
+    }
+    for (int i = tid; i < 2 * Cfg::A_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
 
-    // chunk-invariant staging units: unit u -> (channel quad q, halo pixel)
-    int u_goff[NU], u_lds[NU], u_q[NU];
-    unsigned in_mask = 0;
+    // chunk-invariant staging units: this thread stages channel quad q of halo pixels slot, slot+TPQ, ...
+    const int q = tid / TPQ, slot = tid - q * TPQ;
+    unsigned u_off[NU];          // byte offset of the pixel inside one channel-quad plane
+    int u_lds[NU];
+    bool u_in[NU];
 #pragma unroll
     for (int j = 0; j < NU; j++) {
-        const int u = tid + j * NT;
-        const int q = u / PL;
-        const int pix = u - q * PL;
+        const int pix = slot + j * TPQ;
         const int yy = pix / RS, xx = pix - yy * RS;
         const int y = ty0 + yy - 1, x = tx0 + xx - 1;
-        const bool valid = u < 4 * PL;
-        const bool in = valid && y >= 0 && y < H && x >= 0 && x < W;
-        u_q[j] = valid ? q : 0;
-        u_lds[j] = valid ? pix * PXB + q * 8 : 32;            // bytes 32..47 of pixel 0 are padding: dump slot
-        u_goff[j] = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
-        in_mask |= in ? (1u << j) : 0u;
+        const bool in = pix < PL && y >= 0 && y < H && x >= 0 && x < W;
+        u_in[j] = in;
+        u_lds[j] = pix * PXB + q * 8;
+        u_off[j] = in ? (unsigned)(up ? (y >> 1) * sw + (x >> 1) : y * sw + x) * 16u : 0u;
     }
+    const unsigned q_off = (unsigned)q * plane16;
+    // weight pieces: piece p of the slab -> LDS [hi|lo][tap*32+cout][16 B half]
+    int w_lds[NWP];
+#pragma unroll
+    for (int j = 0; j < NWP; j++) {
+        const int p = tid + j * NT;
+        const int hl = p >= 9 * 32 * 2;
+        const int pp = hl ? p - 9 * 32 * 2 : p;
+        w_lds[j] = hl * Cfg::B_BYTES + (pp >> 1) * PXB + (pp & 1) * 16;
+    }
+    const unsigned char* wslab = g.wsplit + (size_t)tile.gz * g.wchunks * WSLAB + tid * 16;
 
+    const float bj = g.bias[n0 + li];
     f32x16 acc0[RW], acc1[RW];
 #pragma unroll
     for (int r = 0; r < RW; r++)
 #pragma unroll
-        for (int q = 0; q < 16; q++) { acc0[r][q] = 0.f; acc1[r][q] = 0.f; }
+        for (int k = 0; k < 16; k++) { acc0[r][k] = bj; acc1[r][k] = 0.f; }
 
-    float4 pa[NU];
+    f32x4 pa[NU];
     u32x4 pw[NWP];
     auto fetch = [&](int chunk) {
+        const bool fa = chunk < ca16;
+        const int cl = fa ? chunk : chunk - ca16;                         // chunk inside its source
+        const ConvSrc& s = fa ? g.a : g.b;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(s.p) + (size_t)cl * 4 * plane16;
+        const int nq = (pad4(s.C) >> 2) - cl * 4;                          // real quads in this chunk (>= 1)
+        const unsigned qo = q < nq ? q_off : 0u;                           // pad quads re-read quad 0 (their a,b are 0)
 #pragma unroll
-        for (int j = 0; j < NU; j++) {
-            int pq = chunk * (KH / 4) + u_q[j];                 // quad index in the padded-concat space
-            pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
-            pa[j] = load_quad_c4(a4, b4, pq, PA / 4, (unsigned)plane, u_goff[j]);
-        }
+        for (int j = 0; j < NU; j++) pa[j] = *reinterpret_cast<const f32x4*>(base + (u_off[j] + qo));
+        const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
 #pragma unroll
-        for (int j = 0; j < NWP; j++) {
-            int p = tid + j * NT;
-            p = p < 9 * 32 * 4 ? p : 9 * 32 * 4 - 1;
-            const int lo = p >= 9 * 32 * 2;                    // second half of the pieces = lo slab
-            const int pp = lo ? p - 9 * 32 * 2 : p;
-            const int tap = pp >> 6, rr = pp & 63, jj = rr >> 1, hh = rr & 1;
-            const _Float16* src = (lo ? g.wlo : g.whi) + (((size_t)chunk * 9 + tap) * g.coutp + n0 + jj) * KH + hh * 8;
-            pw[j] = *reinterpret_cast<const u32x4*>(src);
-        }
+        for (int j = 0; j < NWP; j++)
+            if ((j + 1) * NT <= WSLAB / 16 || tid + j * NT < WSLAB / 16)  // wave-uniform (WSLAB/16 is a multiple of 64)
+                pw[j] = *reinterpret_cast<const u32x4*>(wsrc + j * NT * 16);
     };
     auto stash = [&](int chunk) {
+        const float slope = chunk < ca16 ? g.a.slope : g.b.slope;
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(tab_a + chunk * KH + q * 4);
+        const f32x4 cb = *reinterpret_cast<const f32x4*>(tab_b + chunk * KH + q * 4);
 #pragma unroll
         for (int j = 0; j < NU; j++) {
-            f16x4 hv, lv;
-            const int pc = (chunk * (KH / 4) + u_q[j]) * 4;
-            const bool ok = (in_mask >> j) & 1u;
-            const float slope = pc < PA ? g.a.slope : g.b.slope;
-            const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
-            float v[4];
+            const f32x4 x = ca * pa[j] + cb;
+            const f32x4 xs = x * slope;
+            f32x4 v;
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const float2 ab = abs_tab[pc + t];               // (0,0) for pad channels
-                const float x = fmaf(ab.x, raw[t], ab.y);
-                const float y = fmaxf(x, x * slope);             // LeakyReLU for 0 < slope <= 1
-                v[t] = ok ? y : 0.0f;
-            }
+            for (int t = 0; t < 4; t++) v[t] = fmaxf(x[t], xs[t]);        // LeakyReLU for 0 < slope <= 1
             // hi = fp16(v) rounded toward zero (any fp16 near v works: lo carries the exact remainder, scaled by 2^11)
-            typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
             const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
             const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
-            const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * 2048.0f,
-                                                                                    (v[1] - (float)h01[1]) * 2048.0f));
-            const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * 2048.0f,
-                                                                                    (v[3] - (float)h23[1]) * 2048.0f));
-            hv[0] = h01[0]; hv[1] = h01[1]; hv[2] = h23[0]; hv[3] = h23[1];
-            lv[0] = l01[0]; lv[1] = l01[1]; lv[2] = l23[0]; lv[3] = l23[1];
-            *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = hv;
-            *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = lv;
-        }
-#pragma unroll
-        for (int j = 0; j < NWP; j++) {
-            const int p = tid + j * NT;
-            if (p < 9 * 32 * 4) {
-                const int lo = p >= 9 * 32 * 2;
-                const int pp = lo ? p - 9 * 32 * 2 : p;
-                const int row = pp >> 1, hh = pp & 1;         // row = tap*32 + jj
-                *reinterpret_cast<u32x4*>((lo ? Blo : Bhi) + row * PXB + hh * 16) = pw[j];
+            const f32x4 hf = {(float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]};
+            const f32x4 d = (v - hf) * 2048.0f;
+            const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
+            const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[2], d[3]));
+            if (u_in[j]) {
+                *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+                *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = f16x4{l01[0], l01[1], l23[0], l23[1]};
             }
         }
+#pragma unroll
+        for (int j = 0; j < NWP; j++)
+            if ((j + 1) * NT <= WSLAB / 16 || tid + j * NT < WSLAB / 16)
+                *reinterpret_cast<u32x4*>(Bhi + w_lds[j]) = pw[j];
     };
 
     fetch(0);
-    __syncthreads();                                           // abs_tab visible
+    __syncthreads();                                           // tables and the zeroed halo visible
     for (int chunk = 0; chunk < g.nchunks; chunk++) {
         stash(chunk);
         __syncthreads();
@@ -536,7 +583,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             for (int ky = 0; ky < 3; ky++) {
                 const int boff = ((ky * 3 + kx) * 32 + li) * PXB + lg * 16;
                 const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bhi + boff);
-                const f16x8 fbl = *reinterpret_cast<const f16x8*>(Blo + boff);
+                const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bhi + Cfg::B_BYTES + boff);
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
                     acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
@@ -548,32 +595,39 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         __syncthreads();
     }
 
-    // ---- epilogue.  D fragment (32x32): register q of lane l = pixel (q&3) + 8*(q>>2) + 4*(l>>5), channel l&31.
-    // Lanes 4k..4k+3 hold the four channels of quad k for the same four pixels; a lane-quad transpose turns that into
-    // one 16-byte C4 store per lane.
+    // ---- epilogue.  D fragment (32x32): register k of lane l = pixel (k&3) + 8*(k>>2) + 4*(l>>5), channel l&31.
+    // Lanes 4c..4c+3 hold the four channels of quad c for the same four pixels; a lane-quad transpose turns that into
+    // one 16-byte C4 store per lane.  Pad channels (j >= cout) come out as exact zeros (zero weights and bias).
     const int j = n0 + li;
-    const bool jok = j < g.cout;
     const bool quad_ok = (j & ~3) < g.cout;
-    const float bj = g.bias[j < g.coutp ? j : 0];
+    const bool interior = ty0 + TH <= H && tx0 + 32 <= W;     // block-uniform
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         const int y = ty0 + wave * RW + r;
+        f32x16 t = acc0[r] + acc1[r] * (1.0f / 2048.0f);
+        if (g.out_lrelu) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
+        }
+        if (interior) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { s1 += t[k]; s2 = fmaf(t[k], t[k], s2); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int x = tx0 + 8 * (k >> 2) + 4 * lg + (k & 3);
+                const float m = (y < H && x < W) ? t[k] : 0.0f;
+                s1 += m; s2 = fmaf(m, m, s2);
+            }
+        }
+        float* orow = g.out + (((size_t)(j >> 2) * H + y) * W + tx0 + 4 * lg + (lane & 3)) * 4;
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
-            const int xb = tx0 + 8 * qq + 4 * lg;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                float t = (acc0[r][qq * 4 + q] + acc1[r][qq * 4 + q] * (1.0f / 2048.0f)) + bj;
-                if (g.out_lrelu) t = lrelu(t, SLOPE);
-                v[q] = jok ? t : 0.0f;
-                if (jok && y < H && xb + q < W) { s1 += t; s2 += t * t; }
-            }
-            quad_transpose(v, lane);
-            const int x = xb + (lane & 3);
-            if (quad_ok && y < H && x < W)
-                *reinterpret_cast<float4*>(g.out + (((size_t)(j >> 2) * H + y) * W + x) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            float v[4] = {t[qq * 4], t[qq * 4 + 1], t[qq * 4 + 2], t[qq * 4 + 3]};
+            quad_transpose_dpp(v, lane);
+            const int x = tx0 + 8 * qq + 4 * lg + (lane & 3);
+            if (quad_ok && y < H && x < W) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
         }
     }
     if (g.partial) {
@@ -588,208 +642,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 for (int w = 1; w < NWV; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
                 g.partial[(size_t)jj * g.nblk + tile.lin] = t;
             }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------- persistent split-fp16 conv
-// Same arithmetic as conv3x3_f16x3, organised for the levels where one launch has thousands of tiles but few chunks:
-//   * ONE workgroup of 512 threads per CU walks the pixel tiles t = blockIdx.x, +gridDim.x, ... (blockIdx.y = output-channel
-//     group), so the per-tile prologue/epilogue and the fetch latency overlap with the neighbouring tiles' work;
-//   * the layer's split-fp16 weights for the group (all chunks) are loaded into LDS ONCE per workgroup; rows are 32 bytes
-//     with the two 16-byte halves XOR-swizzled by bit 3 of the row index (conflict-free ds_read_b128 without padding);
-//   * every wave owns one row of the 8 x 32 tile (acc = 2 x 16 VGPRs) and stages 1/8 of every halo tile: per
-//     (tile, 16-channel chunk) STEP it has two register sets of C4 float4 loads in flight (steps s+2, s+3), writes step
-//     s+1 into the other half of a 2-stage LDS ring and runs the MFMAs of step s; one barrier per step;
-//   * odd waves stage first and multiply second, even waves the other way round, so the two waves of a SIMD keep its
-//     VALU and MFMA pipes busy at the same time.
-constexpr int PXS = 32;            // bytes per pixel / per weight row in the swizzled LDS images
-__device__ __forceinline__ int swz(int row, int h) { return row * PXS + (((h ^ (row >> 3)) & 1) << 4); }
-
-struct ConvCfgP {
-    static constexpr int TH = 8, RS = 34, PL = (TH + 2) * RS;
-    static constexpr int A_HALF = PL * PXS, STAGE = 2 * A_HALF;     // Ahi | Alo
-    static constexpr int W_CHUNK = 9 * 32 * PXS;                     // hi (or lo) weights of one chunk
-    static constexpr int MAX_CHUNKS = 6;
-    static constexpr int NU = (4 * PL + 511) / 512;                  // (channel quad, halo pixel) units per thread
-    static constexpr int MAXC = 208;
-    static size_t lds_bytes(int nchunks) { return 2 * (size_t)STAGE + 2 * (size_t)nchunks * W_CHUNK + 8 * MAXC; }
-};
-
-__global__ __launch_bounds__(512, 2) void conv3x3_f16x3p(const ConvArgsH g) {
-    using Cfg = ConvCfgP;
-    constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU;
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    unsigned char* Wh = dsm + 2 * Cfg::STAGE;
-    unsigned char* Wl = Wh + g.nchunks * Cfg::W_CHUNK;
-    float2* abs_tab = reinterpret_cast<float2*>(Wl + g.nchunks * Cfg::W_CHUNK);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.y * 32;
-    const int H = g.H, W = g.W;
-    const int PA = pad4(g.a.C), pcin = PA + pad4(g.b.C);
-    const int nchunks = g.nchunks;
-    const int ntiles = g.tiles_x * g.tiles_y;
-    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int S = my_tiles * nchunks;
-    const int up = g.a.up;
-    const int sw = up ? (W >> 1) : W;
-    const size_t plane = (size_t)(up ? (H >> 1) : H) * sw;
-    const float4* a4 = reinterpret_cast<const float4*>(g.a.p);
-    const float4* b4 = reinterpret_cast<const float4*>(g.b.p ? g.b.p : g.a.p);
-
-    fill_abs_tab(abs_tab, g.a, g.b, nchunks * KH, tid, 512);
-    for (int p = tid; p < nchunks * 9 * 32 * 2; p += 512) {       // resident weights: 16-byte pieces
-        const int row = p >> 1, hh = p & 1;                        // row = (chunk*9 + tap)*32 + cout
-        const int ct = row >> 5, jj = row & 31;
-        const size_t src = ((size_t)ct * g.coutp + n0 + jj) * KH + hh * 8;
-        *reinterpret_cast<u32x4*>(Wh + swz(row, hh)) = *reinterpret_cast<const u32x4*>(g.whi + src);
-        *reinterpret_cast<u32x4*>(Wl + swz(row, hh)) = *reinterpret_cast<const u32x4*>(g.wlo + src);
-    }
-
-    // chunk- and tile-invariant part of this thread's staging units
-    int u_yx[NU], u_lds[NU], u_q[NU];
-#pragma unroll
-    for (int j = 0; j < NU; j++) {
-        const int u = tid + j * 512;
-        const int q = u / PL, pix = u - q * PL;
-        const int yy = pix / RS, xx = pix - yy * RS;
-        const bool valid = u < 4 * PL;
-        u_q[j] = valid ? q : 0;
-        u_yx[j] = valid ? (yy << 16) | xx : -1;
-        u_lds[j] = swz(pix, q >> 1) + (q & 1) * 8;
-    }
-    float4 pa0[NU], pa1[NU];
-    unsigned m0 = 0, m1 = 0;
-    int f_tile = blockIdx.x, f_chunk = 0, s_chunk = 0;
-    auto fetch = [&](float4 (&pa)[NU], unsigned& mask) {
-        const int ty0 = (f_tile / g.tiles_x) * TH, tx0 = (f_tile % g.tiles_x) * 32;
-        mask = 0;
-#pragma unroll
-        for (int j = 0; j < NU; j++) {
-            const int y = ty0 + (u_yx[j] >> 16) - 1, x = tx0 + (u_yx[j] & 0xffff) - 1;
-            const bool in = u_yx[j] >= 0 && y >= 0 && y < H && x >= 0 && x < W;
-            const int goff = in ? (up ? (y >> 1) * sw + (x >> 1) : y * sw + x) : 0;
-            mask |= in ? (1u << j) : 0u;
-            int pq = f_chunk * (KH / 4) + u_q[j];
-            pq = pq * 4 < pcin ? pq : pcin / 4 - 1;
-            pa[j] = load_quad_c4(a4, b4, pq, PA / 4, (unsigned)plane, goff);
-        }
-        if (++f_chunk == nchunks) { f_chunk = 0; f_tile += gridDim.x; }
-    };
-    auto stash = [&](const float4 (&pa)[NU], unsigned mask, unsigned char* st) {
-        unsigned char* Ahi = st;
-        unsigned char* Alo = st + Cfg::A_HALF;
-#pragma unroll
-        for (int j = 0; j < NU; j++) {
-            const int pc = (s_chunk * (KH / 4) + u_q[j]) * 4;
-            const bool ok = (mask >> j) & 1u;
-            const float slope = pc < PA ? g.a.slope : g.b.slope;
-            const float raw[4] = {pa[j].x, pa[j].y, pa[j].z, pa[j].w};
-            f16x4 hv, lv;
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const float2 ab = abs_tab[pc + t];
-                float v = lrelu(fmaf(ab.x, raw[t], ab.y), slope);
-                v = ok ? v : 0.0f;
-                const _Float16 h = (_Float16)v;
-                hv[t] = h;
-                lv[t] = (_Float16)((v - (float)h) * 2048.0f);
-            }
-            if (u_yx[j] >= 0) {
-                *reinterpret_cast<f16x4*>(Ahi + u_lds[j]) = hv;
-                *reinterpret_cast<f16x4*>(Alo + u_lds[j]) = lv;
-            }
-        }
-        if (++s_chunk == nchunks) s_chunk = 0;
-    };
-
-    // ---- consumer state: this wave's row of the tile
-    const int li = lane & 31, lg = lane >> 5;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int q = 0; q < 16; q++) { acc0[q] = 0.f; acc1[q] = 0.f; }
-    const int j = n0 + li;
-    const bool jok = j < g.cout, quad_ok = (j & ~3) < g.cout;
-    const float bj = g.bias[j < g.coutp ? j : 0];
-    int c_tile = blockIdx.x, c_chunk = 0;
-    auto compute = [&](const unsigned char* st) {
-        const unsigned char* Ahi = st;
-        const unsigned char* Alo = st + Cfg::A_HALF;
-        const unsigned char* Bh = Wh + c_chunk * Cfg::W_CHUNK;      // chunk rows start at a multiple of 288: same swizzle phase
-        const unsigned char* Bl = Wl + c_chunk * Cfg::W_CHUNK;
-#pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
-            f16x8 fah[3], fal[3];
-#pragma unroll
-            for (int hr = 0; hr < 3; hr++) {
-                const int off = swz((wave + hr) * RS + li + kx, lg);
-                fah[hr] = *reinterpret_cast<const f16x8*>(Ahi + off);
-                fal[hr] = *reinterpret_cast<const f16x8*>(Alo + off);
-            }
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
-                const int boff = swz((ky * 3 + kx) * 32 + li, lg);
-                const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bh + boff);
-                const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bl + boff);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ky], fbh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ky], fbl, acc1, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ky], fbh, acc1, 0, 0, 0);
-            }
-        }
-        if (++c_chunk == nchunks) {
-            // tile epilogue for this wave's row: bias (+LReLU), lane-quad transpose, 16-byte C4 stores, BN partials
-            c_chunk = 0;
-            const int y = (c_tile / g.tiles_x) * TH + wave, tx0 = (c_tile % g.tiles_x) * 32;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                const int xb = tx0 + 8 * qq + 4 * lg;
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    float t = (acc0[qq * 4 + q] + acc1[qq * 4 + q] * (1.0f / 2048.0f)) + bj;
-                    if (g.out_lrelu) t = lrelu(t, SLOPE);
-                    v[q] = jok ? t : 0.0f;
-                    if (jok && y < H && xb + q < W) { s1 += t; s2 += t * t; }
-                    acc0[qq * 4 + q] = 0.f; acc1[qq * 4 + q] = 0.f;
-                }
-                quad_transpose(v, lane);
-                const int x = xb + (lane & 3);
-                if (quad_ok && y < H && x < W)
-                    *reinterpret_cast<float4*>(g.out + (((size_t)(j >> 2) * H + y) * W + x) * 4) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-            if (g.partial) {
-                s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-                if (lg == 0 && jok) g.partial[(size_t)j * g.nblk + (size_t)c_tile * 8 + wave] = make_float2(s1, s2);
-            }
-            c_tile += gridDim.x;
-        }
-    };
-
-    // ---- pipeline.  Step s reads ring stage s&1; set pa0 carries even steps, pa1 odd steps.
-    if (S > 0) fetch(pa0, m0);
-    if (S > 1) fetch(pa1, m1);
-    __syncthreads();                                               // abs_tab + weights visible
-    if (S > 0) stash(pa0, m0, dsm);
-    if (S > 2) fetch(pa0, m0);
-    __syncthreads();
-    const bool stage_first = wave & 1;
-    for (int s = 0; s < S; s += 2) {
-        {   // step s from stage 0; stage step s+1 into stage 1
-            const bool more = s + 1 < S;
-            if (stage_first && more) { stash(pa1, m1, dsm + Cfg::STAGE); if (s + 3 < S) fetch(pa1, m1); }
-            compute(dsm);
-            if (!stage_first && more) { stash(pa1, m1, dsm + Cfg::STAGE); if (s + 3 < S) fetch(pa1, m1); }
-            __syncthreads();
-        }
-        if (s + 1 < S) {   // step s+1 from stage 1; stage step s+2 into stage 0
-            const bool more = s + 2 < S;
-            if (stage_first && more) { stash(pa0, m0, dsm); if (s + 4 < S) fetch(pa0, m0); }
-            compute(dsm + Cfg::STAGE);
-            if (!stage_first && more) { stash(pa0, m0, dsm); if (s + 4 < S) fetch(pa0, m0); }
-            __syncthreads();
         }
     }
 }
@@ -1023,10 +875,11 @@ struct LayerW {
     int ca = 0, pcin = 0;   // channels of the first concat source; padded-concat channel count (pad4(ca) + pad4(cin - ca))
     float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
     float2* d_ab_running = nullptr;
-    // split-fp16 copy of the weights for conv3x3_f16x3: [nchunks16][9][coutp32][16] hi and lo*2^11
     float *d_w_d2s = nullptr, *d_bias_d2s = nullptr;   // upsample+conv as a half-resolution conv with 4*cout virtual channels
-    int coutp32 = 0, nchunks16 = 0;
-    _Float16 *d_whi = nullptr, *d_wlo = nullptr;
+    // split-fp16 copy of the weights for conv3x3_f16x3: [coutp32/32][nchunks16][hi | lo*2^11][9][32][16] halfs over the
+    // K16-aligned concat space (source a in chunks [0, ca16), source b after it)
+    int coutp32 = 0, nchunks16 = 0, ca16 = 0;
+    unsigned char* d_wsplit = nullptr;
     float* d_bias32 = nullptr;
 };
 
@@ -1066,12 +919,6 @@ static long f16_min_pixels() {
     return v;
 }
 
-// smallest level that runs on the persistent variant (needs thousands of 8 x 32 tiles to be worth one workgroup per CU)
-static long f16p_min_pixels() {
-    static const long v = getenv("AIPT_F16P_MINPIX") ? atol(getenv("AIPT_F16P_MINPIX")) : (1l << 40);   // off by default: not yet faster, see DESIGN.md
-    return v;
-}
-
 static void build_table(int* cin, int* cout) {
     int n = 0, c_in = 10;
     for (int i = 0; i < 5; i++) {
@@ -1095,7 +942,7 @@ static void build_table(int* cin, int* cout) {
 static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
-        hipFree(l.d_ab_running); hipFree(l.d_whi); hipFree(l.d_wlo); hipFree(l.d_bias32);
+        hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_bias32);
         hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s);
         l = LayerW();
     }
@@ -1130,9 +977,6 @@ static DenoiseState* state(aipt_ctx* ctx) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->dn->num_cus = prop.multiProcessorCount;
-        // the persistent kernel keeps a layer's weights + a 2-stage activation ring in LDS (up to ~156 KB)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
     }
     return ctx->dn;
 }
@@ -1221,33 +1065,14 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         g.nblk = nblk;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16p_min_pixels() && H % 8 == 0 && W % 32 == 0 &&
-               (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH <= ConvCfgP::MAX_CHUNKS) {
-        // thousands of tiles, few chunks: persistent split-fp16 kernel, weights resident in LDS
-        ConvArgsH gh;
-        gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
-        gh.whi = L.d_whi; gh.wlo = L.d_wlo; gh.bias = L.d_bias32;
-        gh.cout = L.cout; gh.coutp = L.coutp32;
-        gh.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH;
-        gh.out = dst.p; gh.out_lrelu = out_lrelu;
-        gh.tiles_x = W / 32; gh.tiles_y = H / 8; gh.groups = L.coutp32 / 32;
-        const int ntiles = gh.tiles_x * gh.tiles_y;
-        nblk = ntiles * 8;                                          // one BN partial per (tile, wave)
-        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        gh.partial = batch ? s->partial : nullptr;
-        gh.nblk = nblk;
-        int gx = s->num_cus / gh.groups;
-        if (gx < 1) gx = 1;
-        if (gx > ntiles) gx = ntiles;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3p");
-        hipLaunchKernelGGL(conv3x3_f16x3p, dim3(gx, gh.groups), dim3(512), ConvCfgP::lds_bytes(gh.nchunks), ctx->stream, gh);
     } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
-        gh.whi = L.d_whi; gh.wlo = L.d_wlo; gh.bias = L.d_bias32;
+        gh.wsplit = L.d_wsplit; gh.bias = L.d_bias32;
         gh.cout = L.cout; gh.coutp = L.coutp32;
-        gh.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KH - 1) / KH;
+        gh.nchunks = g.b.C ? L.nchunks16 : L.ca16;                 // an all-zero second source (hidden reset) is skipped
+        gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
         nblk = grid.x * grid.y;
@@ -1375,27 +1200,30 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             AIPT_HIP(ctx, hipMemcpy(L.d_w_d2s, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
             AIPT_HIP(ctx, hipMemcpy(L.d_bias_d2s, bv.data(), vnp * 4, hipMemcpyHostToDevice));
         }
-        {   // split-fp16 weights
+        {   // split-fp16 weights, pre-tiled per (output-channel group, chunk) slab
+            const int cb = L.cin - L.ca;
             L.coutp32 = (L.cout + 31) / 32 * 32;
-            L.nchunks16 = (L.pcin + KH - 1) / KH;
-            const size_t nh = (size_t)L.nchunks16 * 9 * L.coutp32 * KH;
-            std::vector<_Float16> wh(nh, (_Float16)0.0f), wl(nh, (_Float16)0.0f);
+            L.ca16 = pad16(L.ca) / KH;
+            L.nchunks16 = L.ca16 + pad16(cb) / KH;
+            const size_t nh = (size_t)(L.coutp32 / 32) * L.nchunks16 * (WSLAB / 2);
+            std::vector<_Float16> ws(nh, (_Float16)0.0f);
             for (int j = 0; j < L.cout; j++)
-                for (int c = 0; c < L.cin; c++)
+                for (int c = 0; c < L.cin; c++) {
+                    const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
                     for (int t = 0; t < 9; t++) {
                         const float v = w[((size_t)j * L.cin + c) * 9 + t];
                         const _Float16 h = (_Float16)v;
-                        const size_t o = (((size_t)(pc_of(c) / KH) * 9 + t) * L.coutp32 + j) * KH + (pc_of(c) % KH);
-                        wh[o] = h;
-                        wl[o] = (_Float16)((v - (float)h) * 2048.0f);
+                        const size_t slab = ((size_t)(j / 32) * L.nchunks16 + kc / KH) * (WSLAB / 2);
+                        const size_t o = slab + ((size_t)t * 32 + (j % 32)) * KH + (kc % KH);
+                        ws[o] = h;
+                        ws[o + 9 * 32 * KH] = (_Float16)((v - (float)h) * 2048.0f);
                     }
+                }
             std::vector<float> b32(L.coutp32, 0.0f);
             memcpy(b32.data(), b, 4 * L.cout);
-            AIPT_HIP(ctx, hipMalloc((void**)&L.d_whi, nh * 2));
-            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wlo, nh * 2));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit, nh * 2));
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias32, L.coutp32 * 4));
-            AIPT_HIP(ctx, hipMemcpy(L.d_whi, wh.data(), nh * 2, hipMemcpyHostToDevice));
-            AIPT_HIP(ctx, hipMemcpy(L.d_wlo, wl.data(), nh * 2, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMemcpy(L.d_wsplit, ws.data(), nh * 2, hipMemcpyHostToDevice));
             AIPT_HIP(ctx, hipMemcpy(L.d_bias32, b32.data(), L.coutp32 * 4, hipMemcpyHostToDevice));
         }
         AIPT_HIP(ctx, hipMalloc((void**)&L.d_w, wg.size() * 4));

@@ -94,6 +94,7 @@ ABI = [
     ("aipt_gbuffer", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aipt_frame_set_timing", C.c_int, [_P, C.c_int]),
     ("aipt_frame_last_times", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("aipt_frame_prefetch", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32]),
     ("aipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     ("aipt_scene_release", None, [_P]),
     ("aipt_scene_set_resolution", C.c_int, [_P, C.c_int, C.c_int]),
@@ -336,6 +337,11 @@ class Context:
               bn_batch: bool = True, carry: bool = True):
         flags = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
         self._ck(lib().aipt_frame(self._h, C.byref(cam), iter, depth, trace_flags, flags, _P(out3.data_ptr())))
+
+    def frame_prefetch(self, cam: Camera, iter: int, depth: int, trace_flags: int = TRACE_DEFAULT):
+        """Trace the NEXT frame on the side stream while the current one is denoised; the next frame() call with the
+        same arguments consumes it."""
+        self._ck(lib().aipt_frame_prefetch(self._h, C.byref(cam), iter, depth, trace_flags))
 
     def gbuffer(self):
         """(device pointer, rows, stride) of the context-owned padded G-buffer."""

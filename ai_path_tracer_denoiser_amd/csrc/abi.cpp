@@ -65,6 +65,9 @@ int aipt_create(int device, void* stream, aipt_ctx** out) {
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
     for (auto& ev : ctx->fev) hipEventCreate(&ev);
+    for (auto& ev : ctx->ev_denoised) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_prefetched, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_traced, hipEventDisableTiming);
     *out = ctx;
     return AIPT_OK;
 }
@@ -73,10 +76,14 @@ void aipt_destroy(aipt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     aipt::trace_destroy(ctx);
     aipt::denoise_destroy(ctx);
-    if (ctx->d_gbuf) hipFree(ctx->d_gbuf);
+    for (float* g : ctx->d_gbufs) if (g) hipFree(g);
     if (ctx->d_out_pad) hipFree(ctx->d_out_pad);
+    for (auto& ev : ctx->ev_denoised) if (ev) hipEventDestroy(ev);
+    if (ctx->ev_prefetched) hipEventDestroy(ctx->ev_prefetched);
+    if (ctx->ev_traced) hipEventDestroy(ctx->ev_traced);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (auto& ev : ctx->fev) if (ev) hipEventDestroy(ev);
@@ -94,7 +101,7 @@ const char* aipt_last_error(const aipt_ctx* ctx) {
 
 int aipt_sync(aipt_ctx* ctx) {
     AIPT_CHECK_CTX(ctx);
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     return AIPT_OK;
 }
 
@@ -109,7 +116,7 @@ int aipt_malloc(aipt_ctx* ctx, size_t bytes, void** d_out) {
 
 int aipt_free(aipt_ctx* ctx, void* d_ptr) {
     AIPT_CHECK_CTX(ctx);
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     AIPT_HIP(ctx, hipFree(d_ptr));
     return AIPT_OK;
 }
@@ -117,14 +124,14 @@ int aipt_free(aipt_ctx* ctx, void* d_ptr) {
 int aipt_upload(aipt_ctx* ctx, void* d_dst, const void* h_src, size_t bytes) {
     AIPT_CHECK_CTX(ctx);
     AIPT_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     return AIPT_OK;
 }
 
 int aipt_download(aipt_ctx* ctx, void* h_dst, const void* d_src, size_t bytes) {
     AIPT_CHECK_CTX(ctx);
     AIPT_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     return AIPT_OK;
 }
 
@@ -157,18 +164,25 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_CHECK_CTX(ctx);
     if (width <= 0 || height <= 0) return fail(ctx, AIPT_E_INVALID, "aipt_frame_configure: %dx%d", width, height);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     const int wp = round_up32(width), hp = round_up32(height);   // pad policy: zeros bottom/right
     int rc = aipt_trace_configure(ctx, width, height);
     if (rc) return rc;
     rc = aipt_denoise_configure(ctx, hp, wp);
     if (rc) return rc;
-    if (ctx->d_gbuf) { hipFree(ctx->d_gbuf); ctx->d_gbuf = nullptr; }
+    if (ctx->side) AIPT_HIP(ctx, hipStreamSynchronize(ctx->side));
+    for (float*& g : ctx->d_gbufs) if (g) { hipFree(g); g = nullptr; }
+    ctx->d_gbuf = nullptr; ctx->front = 0; ctx->pf.valid = false;
+    ctx->denoised_valid[0] = ctx->denoised_valid[1] = false;
     if (ctx->d_out_pad) { hipFree(ctx->d_out_pad); ctx->d_out_pad = nullptr; }
     const size_t plane = (size_t)wp * hp;
-    AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_gbuf, sizeof(float) * 10 * plane));
-    // a miss pixel is all-zero in the reference G-buffer; padding uses the same value and is never overwritten
-    AIPT_HIP(ctx, hipMemsetAsync(ctx->d_gbuf, 0, sizeof(float) * 10 * plane, ctx->stream));
+    // two G-buffers: aipt_frame_prefetch traces the next frame into the back one while the front one is denoised.
+    // A miss pixel is all-zero in the reference G-buffer; padding uses the same value and is never overwritten.
+    for (float*& g : ctx->d_gbufs) {
+        AIPT_HIP(ctx, hipMalloc((void**)&g, sizeof(float) * 10 * plane));
+        AIPT_HIP(ctx, hipMemsetAsync(g, 0, sizeof(float) * 10 * plane, ctx->stream));
+    }
+    ctx->d_gbuf = ctx->d_gbufs[0];
     if (wp != width || hp != height) AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_out_pad, sizeof(float) * 3 * plane));
     ctx->fw = width; ctx->fh = height; ctx->fwp = wp; ctx->fhp = hp;
     return AIPT_OK;
@@ -199,8 +213,18 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
         return fail(ctx, AIPT_E_INVALID, "aipt_frame: camera is %dx%d, configured %dx%d", cam->resolution[0],
                     cam->resolution[1], ctx->fw, ctx->fh);
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[0], ctx->stream));
-    int rc = aipt_trace(ctx, cam, iter, depth, trace_flags, ctx->d_gbuf, ctx->fhp, ctx->fwp);
-    if (rc) return rc;
+    int rc;
+    const bool hit = ctx->pf.valid && ctx->pf.iter == iter && ctx->pf.depth == depth && ctx->pf.flags == trace_flags &&
+                     !memcmp(&ctx->pf.cam, cam, sizeof(*cam));
+    ctx->pf.valid = false;                                     // a mismatching prefetch is dropped (its G-buffer is reused)
+    if (hit) {
+        ctx->front = ctx->pf.buf;
+        AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prefetched, 0));
+    } else {                                                   // unpipelined: the front G-buffer stays where it is
+        rc = aipt::trace_on_stream(ctx, ctx->stream, cam, iter, depth, trace_flags, ctx->d_gbufs[ctx->front], ctx->fhp, ctx->fwp);
+        if (rc) return rc;
+    }
+    ctx->d_gbuf = ctx->d_gbufs[ctx->front];
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
     const bool crop = ctx->d_out_pad != nullptr;
     rc = aipt_denoise(ctx, ctx->d_gbuf, crop ? ctx->d_out_pad : d_out3, dn_flags);
@@ -214,10 +238,32 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
                                            ctx->d_out_pad + (size_t)c * ctx->fwp * ctx->fhp, sizeof(float) * ctx->fwp,
                                            sizeof(float) * ctx->fw, (size_t)ctx->fh, hipMemcpyDeviceToDevice, ctx->stream));
     }
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], ctx->stream));
+    ctx->denoised_valid[ctx->front] = true;
     if (ctx->frame_timing) {
         AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
         ctx->frame_timed = true;
     }
+    return AIPT_OK;
+}
+
+int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbuf) return fail(ctx, AIPT_E_STATE, "aipt_frame_prefetch: call aipt_frame_configure first");
+    if (!cam) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: NULL camera");
+    if (cam->resolution[0] != ctx->fw || cam->resolution[1] != ctx->fh)
+        return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: camera is %dx%d, configured %dx%d", cam->resolution[0],
+                    cam->resolution[1], ctx->fw, ctx->fh);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->side) AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    const int back = ctx->front ^ 1;
+    // the denoise that last read the back G-buffer must be done before the trace overwrites it
+    if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_denoised[back], 0));
+    const int rc = aipt::trace_on_stream(ctx, ctx->side, cam, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp);
+    if (rc) return rc;
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
+    ctx->pf.valid = true; ctx->pf.cam = *cam; ctx->pf.iter = iter; ctx->pf.depth = depth; ctx->pf.flags = trace_flags;
+    ctx->pf.buf = back;
     return AIPT_OK;
 }
 

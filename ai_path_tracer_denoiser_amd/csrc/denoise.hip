@@ -735,6 +735,96 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------- single-quad conv
+// dec1.c2 (3 -> 3): one C4 quad in, one out, no concat, no resampling -- 30 MB of traffic and 76 MFLOP, so it is a
+// streaming kernel: one thread per strip of 4 output pixels, the 3 x 6 input neighbourhood in registers (sixteen-byte
+// loads, neighbouring lanes overlap in L1), weights through the scalar cache, one 16-byte store per pixel.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
+    __shared__ float2 red[4][COUT];
+    const int tid = threadIdx.x;
+    const int H = g.H, W = g.W, W4 = (W + 3) >> 2;
+    const int strip = blockIdx.x * 256 + tid;
+    const int y = strip / W4, xs = (strip - y * W4) * 4;
+    const bool live = y < H;
+    const float4* in4 = reinterpret_cast<const float4*>(g.a.p);
+    float ca[CIN], cb[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; c++) {
+        const float2 ab = g.a.ab ? g.a.ab[c] : make_float2(1.0f, 0.0f);
+        ca[c] = ab.x; cb[c] = ab.y;
+    }
+    const float slope = g.a.slope;
+    float v[3][6][CIN];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const int yy = y + r - 1;
+        const bool yin = live && yy >= 0 && yy < H;
+        const int yc = min(max(yy, 0), H - 1);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int xx = xs + i - 1;
+            const bool in = yin && xx >= 0 && xx < W;
+            const float4 raw = in4[(size_t)yc * W + min(max(xx, 0), W - 1)];
+            const float rr[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int c = 0; c < CIN; c++) {
+                const float t = fmaf(ca[c], rr[c], cb[c]);
+                v[r][i][c] = in ? fmaxf(t, t * slope) : 0.0f;       // zero padding in the normalised domain
+            }
+        }
+    }
+    float acc[4][COUT];
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+        for (int j = 0; j < COUT; j++) acc[p][j] = g.bias[j];
+#pragma unroll
+    for (int j = 0; j < COUT; j++)
+#pragma unroll
+        for (int c = 0; c < CIN; c++)
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const float w = g.w_raw[((size_t)j * CIN + c) * 9 + ky * 3 + kx];    // wave-uniform: scalar load
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc[p][j] = fmaf(v[ky][p + kx][c], w, acc[p][j]);
+                }
+    float s1[COUT], s2[COUT];
+#pragma unroll
+    for (int j = 0; j < COUT; j++) { s1[j] = 0.f; s2[j] = 0.f; }
+    float4* out4 = reinterpret_cast<float4*>(g.out);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool ok = live && xs + p < W;
+#pragma unroll
+        for (int j = 0; j < COUT; j++) {
+            float t = acc[p][j];
+            if (g.out_lrelu) t = lrelu(t, SLOPE);
+            o[j] = t;
+            if (ok) { s1[j] += t; s2[j] = fmaf(t, t, s2[j]); }
+        }
+        if (ok) out4[(size_t)y * W + xs + p] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (g.partial) {
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int j = 0; j < COUT; j++) {
+            float a = s1[j], b = s2[j];
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+            if (lane == 0) red[wave][j] = make_float2(a, b);
+        }
+        __syncthreads();
+        if (tid < COUT) {
+            float2 t = red[0][tid];
+            for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
+            g.partial[(size_t)tid * g.nblk + blockIdx.x] = t;
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------------- VALU conv
 // One thread per output element; reads its 9*cin taps straight from HBM.  Only for on-GPU cross-checks.
 __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
@@ -1057,6 +1147,14 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, ctx->stream);
         else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, ctx->stream);
         else launch_mfma<1, 1, 1>(g, grid, ctx->stream);
+    } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
+        const int strips = ((W + 3) / 4) * H;
+        nblk = (strips + 255) / 256;
+        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
+        g.partial = batch ? s->partial : nullptr;
+        g.nblk = nblk;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3>");
+        hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, ctx->stream, g);
     } else if (L.cout == 3 && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         const dim3 grid((W + 15) / 16, (H + 15) / 16);
         nblk = grid.x * grid.y;
@@ -1122,7 +1220,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
     AIPT_CHECK_CTX(ctx);
     if (!blob) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_load_weights: blob is NULL");
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     const uint8_t* p = (const uint8_t*)blob;
     if (bytes < 16 || memcmp(p, "AIPTDW01", 8)) return fail(ctx, AIPT_E_FORMAT, "weight blob: bad magic");
     uint32_t n; memcpy(&n, p + 8, 4);
@@ -1249,7 +1347,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         return fail(ctx, AIPT_E_INVALID, "aipt_denoise_configure: %dx%d is not a positive multiple of 32 "
                     "(5 x MaxPool2d(2) + skip concat, recurrent_autoencoder_model.py:98-107,136-140)", height, width);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     DenoiseState* s = state(ctx);
     if (s->H == height && s->W == width) return AIPT_OK;
     free_activations(s);
@@ -1295,7 +1393,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     s->partial_elems = mx;
     s->H = height; s->W = width;
     s->hidden_valid = false;
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     return AIPT_OK;
 }
 
@@ -1375,7 +1473,7 @@ int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls
     AIPT_CHECK_CTX(ctx);
     DenoiseState* s = state(ctx);
     if (max_calls < 1 || max_calls > 4096) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_profile_begin: max_calls %d", max_calls);
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     free_profile(s);
     s->prof_ev.resize((size_t)max_calls * NLAYERS * 2, nullptr);
     for (int c = 0; c < max_calls; c++)
@@ -1391,7 +1489,7 @@ int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls
 int aipt_denoise_profile_end(aipt_ctx* ctx, double* sum_ms28, int* calls) {
     AIPT_CHECK_CTX(ctx);
     DenoiseState* s = state(ctx);
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     if (sum_ms28) {
         for (int l = 0; l < NLAYERS; l++) sum_ms28[l] = 0.0;
         for (int c = 0; c < s->prof_calls; c++)

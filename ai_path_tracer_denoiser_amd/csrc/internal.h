@@ -29,8 +29,18 @@ struct aipt_ctx {
     aipt::DenoiseState* dn = nullptr;
     // aipt_frame
     int fw = 0, fh = 0, fwp = 0, fhp = 0;
-    float* d_gbuf = nullptr;      // [10][fhp][fwp]
+    float* d_gbuf = nullptr;      // [10][fhp][fwp]: the G-buffer of the last aipt_frame (= d_gbufs[front])
+    float* d_gbufs[2] = {nullptr, nullptr};
+    int front = 0;
     float* d_out_pad = nullptr;   // [3][fhp][fwp] when cropping is needed
+    // aipt_frame_prefetch: the next frame's trace runs on `side` into the back G-buffer while this frame is denoised
+    hipStream_t side = nullptr;
+    hipEvent_t ev_denoised[2] = {nullptr, nullptr};   // last denoise that read d_gbufs[i] has finished
+    hipEvent_t ev_prefetched = nullptr;               // the prefetched trace has finished
+    hipEvent_t ev_traced = nullptr;                   // last trace (any stream) has finished: traces share one path state
+    hipStream_t last_trace_stream = nullptr;
+    bool denoised_valid[2] = {false, false};
+    struct { bool valid = false; aipt_camera cam; int iter = 0, depth = 0; uint32_t flags = 0; int buf = 0; } pf;
 };
 
 namespace aipt {
@@ -57,6 +67,15 @@ struct BvhNode {
 };
 void build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);
 
+// aipt_trace on an explicit stream; orders itself after the previous trace when that ran on another stream
+int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags, float* d_gbuf,
+                    int gbuf_rows, int gbuf_stride);
+// wait for the main stream and, if one exists, the prefetch stream
+inline hipError_t sync_streams(aipt_ctx* ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
+    return e;
+}
 void trace_destroy(aipt_ctx* ctx);
 void denoise_destroy(aipt_ctx* ctx);
 

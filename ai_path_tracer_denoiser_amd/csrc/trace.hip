@@ -564,7 +564,7 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
         if (faces[i].materialid < 0 || faces[i].materialid >= nmaterials)
             return fail(ctx, AIPT_E_INVALID, "face %d: material %d of %d", i, faces[i].materialid, nmaterials);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
     hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
@@ -605,7 +605,7 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
 
 int aipt_scene_free(aipt_ctx* ctx) {
     AIPT_CHECK_CTX(ctx);
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
     hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
@@ -618,7 +618,7 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     if (width <= 0 || height <= 0 || (long)width * height > (1l << 30))
         return fail(ctx, AIPT_E_INVALID, "aipt_trace_configure: %dx%d", width, height);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
     if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
     hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
@@ -642,6 +642,13 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
 int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
                float* d_gbuf, int gbuf_rows, int gbuf_stride) {
     AIPT_CHECK_CTX(ctx);
+    return aipt::trace_on_stream(ctx, ctx->stream, cam, iter, depth, flags, d_gbuf, gbuf_rows, gbuf_stride);
+}
+
+extern "C++" {
+namespace aipt {
+int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags,
+                    float* d_gbuf, int gbuf_rows, int gbuf_stride) {
     TraceState* s = tstate(ctx);
     if (!s->have_scene) return fail(ctx, AIPT_E_STATE, "aipt_trace: no scene uploaded");
     if (!s->d_state) return fail(ctx, AIPT_E_STATE, "aipt_trace: call aipt_trace_configure first");
@@ -663,22 +670,27 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     p.n_live = s->d_nlive;
     p.mat0 = (flags & AIPT_TRACE_RECORD_MAT0) ? s->d_mat0 : nullptr;
     p.image = s->d_image;
-    AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), ctx->stream));
+    if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
+    AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), st));
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
         p.cnt_in = nullptr;
         p.cnt_out = s->d_cnt[0];
         p.live_in = b == 0 ? nullptr : s->d_live[b & 1];
         p.live_out = s->d_live[(b + 1) & 1];
-        if (b == 0) hipLaunchKernelGGL(trace_bounce<true>, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
-        else hipLaunchKernelGGL(trace_bounce<false>, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
-        if (b + 1 < depth) hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, ctx->stream, p);
+        if (b == 0) hipLaunchKernelGGL(trace_bounce<true>, dim3(s->nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(trace_bounce<false>, dim3(s->nblk), dim3(256), 0, st, p);
+        if (b + 1 < depth) hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
     }
     AIPT_HIP(ctx, hipGetLastError());
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
+    ctx->last_trace_stream = st;
     s->last_depth = depth;
     s->mat0_valid = p.mat0 != nullptr;
     return AIPT_OK;
 }
+}  // namespace aipt
+}  // extern "C++"
 
 int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n) {
     AIPT_CHECK_CTX(ctx);
@@ -686,8 +698,9 @@ int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n) {
     if (!s->d_nlive || !s->last_depth) return fail(ctx, AIPT_E_STATE, "aipt_trace_live_counts: no trace has run");
     if (!h_n_live || n < 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace_live_counts: bad arguments");
     std::vector<int> tmp(MAX_DEPTH + 1);
+    if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
     AIPT_HIP(ctx, hipMemcpyAsync(tmp.data(), s->d_nlive, sizeof(int) * (MAX_DEPTH + 1), hipMemcpyDeviceToHost, ctx->stream));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     tmp[0] = s->P;
     for (int i = 0; i < n; i++) h_n_live[i] = i <= s->last_depth ? tmp[i] : 0;
     return AIPT_OK;
@@ -698,8 +711,9 @@ int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n) {
     TraceState* s = tstate(ctx);
     if (!s->mat0_valid) return fail(ctx, AIPT_E_STATE, "aipt_trace_first_hit_materials: last trace did not record them");
     if (!h_mat || n != s->P) return fail(ctx, AIPT_E_INVALID, "aipt_trace_first_hit_materials: n=%d, expected %d", n, s->P);
+    if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
     AIPT_HIP(ctx, hipMemcpyAsync(h_mat, s->d_mat0, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
     return AIPT_OK;
 }
 

@@ -182,7 +182,13 @@ int aipt_denoise_layer_info(aipt_ctx* ctx, int layer, char* kernel, size_t kerne
 int aipt_frame_configure(aipt_ctx* ctx, int width, int height);
 int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags, uint32_t dn_flags,
                float* d_out3);
-/* the context-owned padded G-buffer float[10][Hp][Wp] written by aipt_frame (device pointer) and its padded size */
+/* Throughput pipelining (no reference equivalent: runCuda traces and denoises strictly in turn, main.cpp:143-163).
+ * Starts the path trace of the NEXT frame on a second HIP stream, into the context's back G-buffer, so that it overlaps
+ * the denoise of the frame being processed; the following aipt_frame with an identical (cam, iter, depth, trace_flags)
+ * consumes it instead of tracing.  A different request drops the prefetch.  Results are identical to unpipelined
+ * frames.  aipt_sync waits for both streams. */
+int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
+/* the context-owned padded G-buffer float[10][Hp][Wp] of the last aipt_frame (device pointer) and its padded size */
 int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
 /* per-stage GPU time of the last aipt_frame with timing enabled (ms; synchronous) */
 int aipt_frame_set_timing(aipt_ctx* ctx, int enabled);

@@ -37,3 +37,40 @@ def test_frame_sequence_matches_oracle():
         y_ref = orc.forward(gp, True, k > 0)[:, :H, :W]
         assert np.abs(out.cpu().numpy() - y_ref).max() <= 1e-3
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_prefetch_pipeline_is_bit_identical():
+    """aipt_frame_prefetch (trace k+1 on the side stream during denoise k) must not change any output bit."""
+    import torch
+    W, H, depth = 80, 48, 4                # pads to 96 x 64: the crop path is pipelined too
+    sc = api.Scene(CORNELL, res=(W, H), depth=depth)
+    blob = synth.make_blob(7)
+
+    def cams():
+        out = []
+        for k in range(4):
+            c = api.Camera.from_buffer_copy(bytes(sc.camera))
+            api.lib().aipt_camera_orbit(c, sc.zoom, sc.phi + 0.1 * k, sc.theta)
+            out.append(c)
+        return out
+
+    def run(pipelined):
+        ctx = api.Context(0)
+        ctx.pathtrace_init(sc.geoms, sc.materials, sc.faces, None)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        out = torch.empty(3, H, W, device="cuda")
+        res = []
+        cs = cams()
+        for k, c in enumerate(cs):
+            ctx.frame(c, 1, depth, out, bn_batch=True, carry=k > 0)
+            if pipelined and k + 1 < len(cs):
+                ctx.frame_prefetch(cs[k + 1], 1, depth)
+            ctx.sync()
+            res.append(out.cpu().numpy().copy())
+        return res
+
+    a, b = run(False), run(True)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), f"frame {k} differs under prefetch"

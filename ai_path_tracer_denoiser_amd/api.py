@@ -86,6 +86,7 @@ ABI = [
     ("aipt_denoise_get_hidden", C.c_int, [_P, C.c_int, _P]),
     ("aipt_denoise_set_hidden", C.c_int, [_P, C.c_int, _P]),
     ("aipt_denoise_profile_begin", C.c_int, [_P, C.c_uint32, C.c_int]),
+    ("aipt_denoise_profile_stride", C.c_int, [_P, C.c_int]),
     ("aipt_denoise_profile_end", C.c_int, [_P, _P, C.POINTER(C.c_int)]),
     ("aipt_denoise_layer_info", C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4
      + [C.POINTER(C.c_double)]),
@@ -320,6 +321,9 @@ class Context:
         n = C.c_int()
         self._ck(lib().aipt_denoise_profile_end(self._h, ms.ctypes.data, C.byref(n)))
         return ms, n.value
+
+    def profile_stride(self, every: int):
+        self._ck(lib().aipt_denoise_profile_stride(self._h, every))
 
     def layer_info(self, layer: int):
         name = C.create_string_buffer(64)

@@ -998,6 +998,7 @@ struct DenoiseState {
     // per-layer HIP-event profiling (aipt_denoise_profile_*)
     uint32_t prof_mask = 0;
     int prof_max = 0, prof_calls = 0;
+    int prof_every = 1, prof_seen = 0;   // sample every prof_every-th forward (aipt_denoise_profile_stride)
     std::vector<hipEvent_t> prof_ev;     // [call][layer][2]
     char kname[NLAYERS][40] = {};        // kernel that ran each layer in the last forward
 };
@@ -1121,7 +1122,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     if (expect != L.cin || A.C != L.ca)
         return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
     int nblk = 1, fin_groups = 1, fin_stride = 0;
-    const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max;
+    const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], ctx->stream));
     if (s->impl == AIPT_DN_IMPL_VALU) {
@@ -1465,7 +1466,10 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
     }
     AIPT_HIP(ctx, hipGetLastError());
     s->hidden_valid = true;
-    if (s->prof_mask && s->prof_calls < s->prof_max) s->prof_calls++;
+    if (s->prof_mask) {
+        if (s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0) s->prof_calls++;
+        s->prof_seen++;
+    }
     return li == NLAYERS ? AIPT_OK : fail(ctx, AIPT_E_STATE, "aipt_denoise: ran %d layers", li);
 }
 
@@ -1483,6 +1487,14 @@ int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls
     s->prof_mask = layer_mask & ((1u << NLAYERS) - 1u);
     s->prof_max = max_calls;
     s->prof_calls = 0;
+    s->prof_seen = 0;
+    return AIPT_OK;
+}
+
+int aipt_denoise_profile_stride(aipt_ctx* ctx, int every) {
+    AIPT_CHECK_CTX(ctx);
+    if (every < 1) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_profile_stride: every %d", every);
+    state(ctx)->prof_every = every;
     return AIPT_OK;
 }
 

@@ -132,6 +132,7 @@ def main():
     prof_layers = None
     if args.warmup > 0 and not args.no_roofline_events:
         nprof = min(3, args.warmup)
+        ctx.profile_stride(1)
         ctx.profile_begin((1 << 28) - 1, nprof)
     for k in range(args.warmup):
         run_frame(k)
@@ -154,12 +155,17 @@ def main():
     barrier()
 
     # ---- timed region: exactly K frames
+    # HIP-event pairs around the dominant kernel's launches, on the launch stream, on every 4th frame of the timed
+    # region (each pair costs the stream ~2 us; all frames would cost 4 % of `value`)
+    PROF_EVERY = 4
     if prof_layers:
-        ctx.profile_begin(sum(1 << l for l in prof_layers), args.steps)
-    ctx.frame_set_timing(True)
+        ctx.profile_stride(PROF_EVERY)
+        ctx.profile_begin(sum(1 << l for l in prof_layers), (args.steps + PROF_EVERY - 1) // PROF_EVERY)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.warmup, per_rank):
+        if k == per_rank - 1:
+            ctx.frame_set_timing(True)                    # trace/denoise split of the last frame only
         run_frame(k)
     torch.cuda.synchronize(dev)
     barrier()
@@ -212,6 +218,7 @@ def main():
                 "frac": hbm["frac"] if hbm_bound else mfma["frac"],
                 "traffic": traffic,
                 "kernel": dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
+                "launches_timed": launches,
                 "algorithmic_bytes_per_launch": bytes_per_frame / len(prof_layers),
                 "flops_per_launch": flops_per_frame / len(prof_layers),
                 "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma": mfma, "hbm": hbm,

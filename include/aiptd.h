@@ -171,6 +171,8 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src);
  * (0..27, network order); up to max_calls forward passes are recorded; _end synchronises and returns the summed ms. */
 int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls);
 int aipt_denoise_profile_end(aipt_ctx* ctx, double* sum_ms28, int* calls);
+/* time only every `every`-th forward pass after _begin (default 1): each event pair costs the stream ~2 us */
+int aipt_denoise_profile_stride(aipt_ctx* ctx, int every);
 /* kernel instantiation that ran `layer` in the last forward, its shape and algorithmic FLOPs (2*9*cin*cout*h*w) */
 int aipt_denoise_layer_info(aipt_ctx* ctx, int layer, char* kernel, size_t kernel_len, int* cin, int* cout,
                             int* height, int* width, double* flops);

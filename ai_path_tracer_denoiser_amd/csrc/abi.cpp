@@ -80,7 +80,6 @@ void aipt_destroy(aipt_ctx* ctx) {
     aipt::trace_destroy(ctx);
     aipt::denoise_destroy(ctx);
     for (float* g : ctx->d_gbufs) if (g) hipFree(g);
-    if (ctx->d_out_pad) hipFree(ctx->d_out_pad);
     for (auto& ev : ctx->ev_denoised) if (ev) hipEventDestroy(ev);
     if (ctx->ev_prefetched) hipEventDestroy(ctx->ev_prefetched);
     if (ctx->ev_traced) hipEventDestroy(ctx->ev_traced);
@@ -174,7 +173,6 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     for (float*& g : ctx->d_gbufs) if (g) { hipFree(g); g = nullptr; }
     ctx->d_gbuf = nullptr; ctx->front = 0; ctx->pf.valid = false;
     ctx->denoised_valid[0] = ctx->denoised_valid[1] = false;
-    if (ctx->d_out_pad) { hipFree(ctx->d_out_pad); ctx->d_out_pad = nullptr; }
     const size_t plane = (size_t)wp * hp;
     // two G-buffers: aipt_frame_prefetch traces the next frame into the back one while the front one is denoised.
     // A miss pixel is all-zero in the reference G-buffer; padding uses the same value and is never overwritten.
@@ -183,7 +181,6 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
         AIPT_HIP(ctx, hipMemsetAsync(g, 0, sizeof(float) * 10 * plane, ctx->stream));
     }
     ctx->d_gbuf = ctx->d_gbufs[0];
-    if (wp != width || hp != height) AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_out_pad, sizeof(float) * 3 * plane));
     ctx->fw = width; ctx->fh = height; ctx->fwp = wp; ctx->fhp = hp;
     return AIPT_OK;
 }
@@ -226,18 +223,9 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     }
     ctx->d_gbuf = ctx->d_gbufs[ctx->front];
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
-    const bool crop = ctx->d_out_pad != nullptr;
-    rc = aipt_denoise(ctx, ctx->d_gbuf, crop ? ctx->d_out_pad : d_out3, dn_flags);
+    // the final normalisation pass writes the cropped [3][h][w] image directly (no padded copy, no crop copies)
+    rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw);
     if (rc) return rc;
-    if (crop) {
-        // [3][hp][wp] -> [3][h][w]
-        AIPT_HIP(ctx, hipMemcpy2DAsync(d_out3, sizeof(float) * ctx->fw, ctx->d_out_pad, sizeof(float) * ctx->fwp,
-                                       sizeof(float) * ctx->fw, (size_t)ctx->fh, hipMemcpyDeviceToDevice, ctx->stream));
-        for (int c = 1; c < 3; c++)
-            AIPT_HIP(ctx, hipMemcpy2DAsync(d_out3 + (size_t)c * ctx->fw * ctx->fh, sizeof(float) * ctx->fw,
-                                           ctx->d_out_pad + (size_t)c * ctx->fwp * ctx->fhp, sizeof(float) * ctx->fwp,
-                                           sizeof(float) * ctx->fw, (size_t)ctx->fh, hipMemcpyDeviceToDevice, ctx->stream));
-    }
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], ctx->stream));
     ctx->denoised_valid[ctx->front] = true;
     if (ctx->frame_timing) {

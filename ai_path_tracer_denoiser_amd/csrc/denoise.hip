@@ -39,9 +39,48 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // four channels of a pixel -- the unit the conv kernels stage (measured 6.1 TB/s of halo fetch vs 2.9 TB/s with 4-byte
 // loads from planar tensors, tools/membench.hip).  Pad channels of the last quad hold 0.  Only the network input (the
 // G-buffer contract is planar, pathtrace.cu:81-94) and the API-facing outputs are planar.
+// How a consumer obtains the per-channel affine (a, b) of a tensor (y = lrelu(a*x + b)).  Batch-statistics BatchNorm: the
+// producing conv left per-channel sums in `stat` (fp64 atomics into NSLOT replicas, slot = workgroup % NSLOT: 3680
+// workgroups x 64 atomics cost 1.6 us that way, tools/atomicbench.hip) and every consumer workgroup turns them into
+// (a, b) itself in its prologue -- there is no finalize launch between two convs (28 launches x 4.1 us per frame).
+// fp64 sums of fp32 partials are exact for any realistic spread of magnitudes, so the result does not depend on the order
+// of the atomics.  Running statistics / identity: `ab` (or nothing).
+constexpr int NSLOT = 8;
+struct BnRef {
+    const float2* ab;      // explicit affine; with stat == nullptr and ab == nullptr: identity
+    const double* stat;    // [NSLOT][sc][2]: sum, sum of squares
+    const float* gamma;
+    const float* beta;
+    int sc;                // channel stride of stat
+    double inv_n;          // 1 / (pixels the sums run over)
+};
+__device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
+    if (r.stat) {
+        double sx = 0.0, sxx = 0.0;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            sx += r.stat[((size_t)k * r.sc + c) * 2];
+            sxx += r.stat[((size_t)k * r.sc + c) * 2 + 1];
+        }
+        const double mean = sx * r.inv_n;
+        double var = sxx * r.inv_n - mean * mean;          // biased variance, as torch normalises with
+        if (var < 0) var = 0;
+        // the cancellation-prone part (mean, variance) is fp64; scale and shift are fp32 like the tensors they multiply
+        const float sc = r.gamma[c] * rsqrtf((float)(var + 1e-5));
+        return make_float2(sc, fmaf(-(float)mean, sc, r.beta[c]));
+    }
+    return r.ab ? r.ab[c] : make_float2(1.0f, 0.0f);
+}
+// a workgroup's BN sums of channel c (already reduced over the workgroup) -> the producer's stat table
+__device__ __forceinline__ void bn_accumulate(double* stat, int sc, int c, float sum, float sumsq) {
+    double* a = stat + ((size_t)(blockIdx.x % NSLOT) * sc + c) * 2;
+    atomicAdd(a, (double)sum);
+    atomicAdd(a + 1, (double)sumsq);
+}
+
 struct ConvSrc {
     const float* p;      // C4: [ceil(C/4)][sh][sw][4]   (planar != 0: [C][sh][sw])
-    const float2* ab;    // per-channel affine, nullptr = identity
+    BnRef bn;            // per-channel affine
     int C;
     int up;              // 1: stored at half resolution, nearest-upsampled on load
     float slope;         // LeakyReLU slope applied after the affine (1 = none)
@@ -60,8 +99,8 @@ struct ConvArgs {
     int cin, cout, NP, nchunks;
     float* out;          // [cout][H][W] raw
     int out_lrelu;
-    float2* partial;     // [cout][nblk]
-    int nblk;
+    double* stat;        // BN sums of the output (nullptr: not wanted), [NSLOT][sc][2]
+    int sc;
     int d2s;             // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to out[j][2y+a][2x+b]
     int tiles_x, tiles_y, groups;   // pixel tiles and output-channel groups of the launch (1-D XCD-aware grid)
 };
@@ -94,10 +133,8 @@ __device__ __forceinline__ float load_src(const ConvSrc& s, int ch, int y, int x
     const int sy = s.up ? (y >> 1) : y, sx = s.up ? (x >> 1) : x;
     float v = s.planar ? s.p[((size_t)ch * sh + sy) * sw + sx]
                        : s.p[(((size_t)(ch >> 2) * sh + sy) * sw + sx) * 4 + (ch & 3)];
-    if (s.ab) {
-        const float2 ab = s.ab[ch];
-        v = fmaf(ab.x, v, ab.y);
-    }
+    const float2 ab = bn_ab(s.bn, ch);
+    v = fmaf(ab.x, v, ab.y);
     return lrelu(v, s.slope);
 }
 
@@ -107,8 +144,8 @@ __device__ __forceinline__ void fill_abs_tab(float2* abs_tab, const ConvSrc& a, 
     const int PA = pad4(a.C);
     for (int pc = tid; pc < entries; pc += nthreads) {
         float2 t = make_float2(0.0f, 0.0f);
-        if (pc < PA) { if (pc < a.C) t = a.ab ? a.ab[pc] : make_float2(1.0f, 0.0f); }
-        else if (pc - PA < b.C) t = b.ab ? b.ab[pc - PA] : make_float2(1.0f, 0.0f);
+        if (pc < PA) { if (pc < a.C) t = bn_ab(a.bn, pc); }
+        else if (pc - PA < b.C) t = bn_ab(b.bn, pc - PA);
         abs_tab[pc] = t;
     }
 }
@@ -340,7 +377,7 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
             }
         }
     }
-    if (g.partial) {
+    if (g.stat) {
         float2* red = reinterpret_cast<float2*>(smem);     // [4 waves][NBB*16]; the last loop barrier already passed
 #pragma unroll
         for (int n = 0; n < NBB; n++) {
@@ -355,7 +392,7 @@ __global__ __launch_bounds__(256, (RW * MBX * NBB >= 12) ? 2 : (RW * MBX * NBB >
             if (j < g.cout) {
                 float2 t = red[tid];
                 for (int w = 1; w < 4; w++) { t.x += red[w * (NBB * 16) + tid].x; t.y += red[w * (NBB * 16) + tid].y; }
-                g.partial[(size_t)j * g.nblk + tile.lin] = t;
+                bn_accumulate(g.stat, g.sc, g.d2s ? j % g.d2s : j, t.x, t.y);   // d2s: the 4 parities of a channel share its sums
             }
         }
     }
@@ -406,8 +443,8 @@ struct ConvArgsH {
     int wchunks;                   // chunks per group in wsplit
     float* out;
     int out_lrelu;
-    float2* partial;
-    int nblk;
+    double* stat;                  // BN sums of the output (nullptr: not wanted), [NSLOT][sc][2]
+    int sc;
     int tiles_x, tiles_y, groups;
 };
 
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const int c = fa ? kc : kc - ca16 * KH;
         const ConvSrc& s = fa ? g.a : g.b;
         float2 t = make_float2(0.0f, 0.0f);
-        if (c < s.C) t = s.ab ? s.ab[c] : make_float2(1.0f, 0.0f);
+        if (c < s.C) t = bn_ab(s.bn, c);
         tab_a[kc] = t.x;
         tab_b[kc] = t.y;
     }
@@ -630,7 +667,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             if (quad_ok && y < H && x < W) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
         }
     }
-    if (g.partial) {
+    if (g.stat) {
         float2* red = reinterpret_cast<float2*>(smem);         // [NWV waves][32]; the last loop barrier already passed
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (lg == 0) red[wave * 32 + li] = make_float2(s1, s2);
@@ -640,7 +677,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             if (jj < g.cout) {
                 float2 t = red[tid];
                 for (int w = 1; w < NWV; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
-                g.partial[(size_t)jj * g.nblk + tile.lin] = t;
+                bn_accumulate(g.stat, g.sc, jj, t.x, t.y);
             }
         }
     }
@@ -656,6 +693,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
     constexpr int TS = 16, CK = 16;
     __shared__ float tile[CK * 18 * 18];
     __shared__ float2 red[4][COUT];
+    __shared__ float2 abt[224];                                     // (a, b) of every input channel (concat order)
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS;
     const int H = g.H, W = g.W;
@@ -665,6 +703,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
     const int py0 = up ? ((ty0 - 1) >> 1) : ty0 - 1, px0 = up ? ((tx0 - 1) >> 1) : tx0 - 1;   // arithmetic shift: -1 -> -1
     const int PH = up ? 10 : 18, PW = up ? 10 : 18;
     const int aC = g.a.C, ctot = g.a.C + g.b.C;
+    for (int c = tid; c < ctot; c += 256) abt[c] = c < aC ? bn_ab(g.a.bn, c) : bn_ab(g.b.bn, c - aC);
     float acc[COUT];
 #pragma unroll
     for (int j = 0; j < COUT; j++) acc[j] = 0.f;
@@ -681,7 +720,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
                 const int ch = cg < aC ? cg : cg - aC;
                 v = src.planar ? src.p[((size_t)ch * sh + sy) * sw + sx]
                                : src.p[(((size_t)(ch >> 2) * sh + sy) * sw + sx) * 4 + (ch & 3)];
-                if (src.ab) { const float2 ab = src.ab[ch]; v = fmaf(ab.x, v, ab.y); }
+                { const float2 ab = abt[cg]; v = fmaf(ab.x, v, ab.y); }
                 v = lrelu(v, src.slope);
             }
             tile[e] = v;
@@ -718,7 +757,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
         if (ok && j < g.cout) g.out[(((size_t)(j >> 2) * H + y) * W + x) * 4 + (j & 3)] = t;
         s1[j] = ok ? t : 0.f; s2[j] = ok ? t * t : 0.f;
     }
-    if (g.partial) {
+    if (g.stat) {
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int j = 0; j < COUT; j++) {
@@ -730,7 +769,9 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
         if (tid < COUT && tid < g.cout) {
             float2 t = red[0][tid];
             for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
-            g.partial[(size_t)tid * g.nblk + blockIdx.y * gridDim.x + blockIdx.x] = t;
+            double* st = g.stat + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) % NSLOT) * g.sc + tid) * 2;
+            atomicAdd(st, (double)t.x);
+            atomicAdd(st + 1, (double)t.y);
         }
     }
 }
@@ -751,7 +792,7 @@ __global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
     float ca[CIN], cb[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; c++) {
-        const float2 ab = g.a.ab ? g.a.ab[c] : make_float2(1.0f, 0.0f);
+        const float2 ab = bn_ab(g.a.bn, c);                       // wave-uniform: scalar loads
         ca[c] = ab.x; cb[c] = ab.y;
     }
     const float slope = g.a.slope;
@@ -808,7 +849,7 @@ __global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
         }
         if (ok) out4[(size_t)y * W + xs + p] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (g.partial) {
+    if (g.stat) {
         const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
         for (int j = 0; j < COUT; j++) {
@@ -820,7 +861,7 @@ __global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
         if (tid < COUT) {
             float2 t = red[0][tid];
             for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
-            g.partial[(size_t)tid * g.nblk + blockIdx.x] = t;
+            bn_accumulate(g.stat, g.sc, tid, t.x, t.y);
         }
     }
 }
@@ -847,7 +888,7 @@ __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
 }
 
 // per-channel sum / sum-of-squares of a stored tensor (VALU path only): one block per channel
-__global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, float2* partial) {
+__global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, double* stat) {
     const int c = blockIdx.x;
     const float* p = t + (size_t)(c >> 2) * hw * 4 + (c & 3);      // C4 layout
     double a = 0, b = 0;
@@ -859,86 +900,51 @@ __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, 
         if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = make_float2((float)sa[0], (float)sb[0]);
-}
-
-// -------------------------------------------------------------------------------------------------- BN finalize
-// One block per channel: fixed-order fp64 tree over the conv blocks' partials -> (a, b).  running != nullptr copies
-// the precomputed running-statistics affine instead.
-__global__ __launch_bounds__(256) void bn_finalize(const float2* partial, int nblk, double inv_n, const float* gamma,
-                                                   const float* beta, const float2* running, float2* ab, int groups,
-                                                   int gstride) {
-    const int c = blockIdx.x;
-    if (running) {
-        if (threadIdx.x == 0) ab[c] = running[c];
-        return;
-    }
-    // channel c owns `groups` rows of the partial table (depth-to-space convs: one row per output parity)
-    double a = 0, b = 0;
-    for (int gi = 0; gi < groups; gi++)
-        for (int i = threadIdx.x; i < nblk; i += 256) {
-            const float2 p = partial[(size_t)(c + gi * gstride) * nblk + i];
-            a += p.x; b += p.y;
-        }
-    __shared__ double sa[256], sb[256];
-    sa[threadIdx.x] = a; sb[threadIdx.x] = b;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const double mean = sa[0] * inv_n;
-        double var = sb[0] * inv_n - mean * mean;      // biased variance, as torch normalises with
-        if (var < 0) var = 0;
-        const double sc = (double)gamma[c] / sqrt(var + (double)BN_EPS);
-        ab[c] = make_float2((float)sc, (float)((double)beta[c] - mean * sc));
-    }
+    if (threadIdx.x == 0) { stat[blockIdx.x * 2] = sa[0]; stat[blockIdx.x * 2 + 1] = sb[0]; }   // slot 0 of a zeroed table
 }
 
 // -------------------------------------------------------------------------------------------------- elementwise
-// out = MaxPool2d(2) of the normalised tensor lrelu(a*raw+b); C4 in, C4 out: one thread per (channel quad, pooled pixel)
-__global__ __launch_bounds__(256) void pool2_norm(const float* raw, const float2* ab, float slope, int C, int H, int W,
+// out = MaxPool2d(2) of the normalised tensor lrelu(a*raw+b); C4 in, C4 out: blockIdx.y = channel quad (its four (a, b)
+// are wave-uniform: scalar loads), one thread per pooled pixel
+__global__ __launch_bounds__(256) void pool2_norm(const float* raw, const BnRef bn, float slope, int C, int H, int W,
                                                   float* out) {
-    const int h = H >> 1, w = W >> 1, C4 = (C + 3) >> 2;
-    const size_t n = (size_t)C4 * h * w;
-    const float4* in4 = reinterpret_cast<const float4*>(raw);
-    float4* out4 = reinterpret_cast<float4*>(out);
+    const int h = H >> 1, w = W >> 1, q = blockIdx.y;
+    const size_t n = (size_t)h * w;
+    const float4* in4 = reinterpret_cast<const float4*>(raw) + (size_t)q * H * W;
+    float4* out4 = reinterpret_cast<float4*>(out) + (size_t)q * n;
+    float2 f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = q * 4 + k < C ? bn_ab(bn, q * 4 + k) : make_float2(0.0f, 0.0f);   // pad channels stay 0
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int x = (int)(i % w);
-        const size_t t = i / w;
-        const int y = (int)(t % h), q = (int)(t / h);
-        const float4* p = in4 + ((size_t)q * H + 2 * y) * W + 2 * x;
+        const int x = (int)(i % w), y = (int)(i / w);
+        const float4* p = in4 + (size_t)(2 * y) * W + 2 * x;
         const float4 r[4] = {p[0], p[1], p[W], p[W + 1]};
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int c = q * 4 + k;
-            float m = 0.0f;                                        // pad channels stay 0
-            if (c < C) {
-                const float2 f = ab[c];
-                const float e0 = k == 0 ? r[0].x : k == 1 ? r[0].y : k == 2 ? r[0].z : r[0].w;
-                const float e1 = k == 0 ? r[1].x : k == 1 ? r[1].y : k == 2 ? r[1].z : r[1].w;
-                const float e2 = k == 0 ? r[2].x : k == 1 ? r[2].y : k == 2 ? r[2].z : r[2].w;
-                const float e3 = k == 0 ? r[3].x : k == 1 ? r[3].y : k == 2 ? r[3].z : r[3].w;
-                m = fmaxf(fmaxf(lrelu(fmaf(f.x, e0, f.y), slope), lrelu(fmaf(f.x, e1, f.y), slope)),
-                          fmaxf(lrelu(fmaf(f.x, e2, f.y), slope), lrelu(fmaf(f.x, e3, f.y), slope)));
-            }
-            o[k] = m;
+            const float e0 = k == 0 ? r[0].x : k == 1 ? r[0].y : k == 2 ? r[0].z : r[0].w;
+            const float e1 = k == 0 ? r[1].x : k == 1 ? r[1].y : k == 2 ? r[1].z : r[1].w;
+            const float e2 = k == 0 ? r[2].x : k == 1 ? r[2].y : k == 2 ? r[2].z : r[2].w;
+            const float e3 = k == 0 ? r[3].x : k == 1 ? r[3].y : k == 2 ? r[3].z : r[3].w;
+            o[k] = fmaxf(fmaxf(lrelu(fmaf(f[k].x, e0, f[k].y), slope), lrelu(fmaf(f[k].x, e1, f[k].y), slope)),
+                         fmaxf(lrelu(fmaf(f[k].x, e2, f[k].y), slope), lrelu(fmaf(f[k].x, e3, f[k].y), slope)));
         }
         out4[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
-// planar out[c][i] = lrelu(a*raw+b) of a C4 tensor (network output, hidden-state export)
-__global__ __launch_bounds__(256) void apply_norm(const float* raw, const float2* ab, float slope, int C, size_t hw,
-                                                  float* out) {
-    const size_t n = (size_t)C * hw;
+// planar out[c][y][x] = lrelu(a*raw+b) of a C4 tensor [.][H][W][4], cropped to oh x ow (network output: the frame's
+// padding is dropped here; hidden-state export: oh = H, ow = W).  blockIdx.y = channel.
+__global__ __launch_bounds__(256) void apply_norm(const float* raw, const BnRef bn, float slope, int H, int W, float* out,
+                                                  int oh, int ow) {
+    const int c = blockIdx.y;
+    const float2 f = bn_ab(bn, c);
+    const float* src = raw + (size_t)(c >> 2) * H * W * 4 + (c & 3);
+    float* dst = out + (size_t)c * oh * ow;
+    const size_t n = (size_t)oh * ow;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i / hw);
-        const size_t px = i - (size_t)c * hw;
-        const float2 f = ab[c];
-        out[i] = lrelu(fmaf(f.x, raw[((size_t)(c >> 2) * hw + px) * 4 + (c & 3)], f.y), slope);
+        const int y = (int)(i / ow), x = (int)(i - (size_t)y * ow);
+        dst[i] = lrelu(fmaf(f.x, src[((size_t)y * W + x) * 4], f.y), slope);
     }
 }
 
@@ -952,11 +958,6 @@ __global__ __launch_bounds__(256) void planar_to_c4(const float* in, int C, size
         const int c = (int)(t / hw) * 4 + k;
         out[i] = c < C ? in[(size_t)c * hw + px] : 0.0f;
     }
-}
-
-__global__ void fill_ab_identity(float2* ab, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < C) ab[i] = make_float2(1.0f, 0.0f);
 }
 
 // -------------------------------------------------------------------------------------------------- host side
@@ -975,7 +976,7 @@ struct LayerW {
 
 struct Tensor {
     float* p = nullptr;     // C4 layout unless planar
-    float2* ab = nullptr;
+    BnRef bn = {nullptr, nullptr, nullptr, nullptr, 0, 0.0};   // identity until a conv produces the tensor
     int C = 0;
     float slope = SLOPE;
     int planar = 0;
@@ -989,8 +990,12 @@ struct DenoiseState {
     Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
     Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
     Tensor D1[6], D2[6];           // decoder k = 1..5
-    float2* partial = nullptr;
-    size_t partial_elems = 0;
+    // BN sums of every conv layer, double-buffered by frame parity: the hidden states written in frame k are read in
+    // frame k+1, whose own sums go to the other set (one memset per frame instead of a finalize launch per conv)
+    static constexpr int STAT_SC = 128;                                    // channel stride (>= every cout)
+    static constexpr size_t STAT_LAYER = (size_t)NSLOT * STAT_SC * 2;      // doubles per layer
+    double* stat[2] = {nullptr, nullptr};
+    int parity = 0;
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
     int num_cus = 256;
@@ -1049,7 +1054,7 @@ static void free_profile(DenoiseState* s) {
 static void free_activations(DenoiseState* s) {
     for (void* p : s->allocs) hipFree(p);
     s->allocs.clear();
-    s->partial = nullptr;
+    s->stat[0] = s->stat[1] = nullptr;
     s->H = s->W = 0;
 }
 
@@ -1108,9 +1113,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
                     int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b) {
     const LayerW& L = s->L[li];
     ConvArgs g;
-    g.a = ConvSrc{A.p, A.ab, A.C, upA, A.slope, A.planar};
-    if (B && use_b) g.b = ConvSrc{B->p, B->ab, B->C, upB, B->slope, B->planar};
-    else g.b = ConvSrc{nullptr, nullptr, 0, 0, 1.0f, 0};
+    g.a = ConvSrc{A.p, A.bn, A.C, upA, A.slope, A.planar};
+    if (B && use_b) g.b = ConvSrc{B->p, B->bn, B->C, upB, B->slope, B->planar};
+    else g.b = ConvSrc{nullptr, BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0}, 0, 0, 1.0f, 0};
     g.H = H; g.W = W;
     g.w = L.d_w; g.w_raw = L.d_w_raw; g.bias = L.d_bias;
     g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
@@ -1121,16 +1126,16 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin || A.C != L.ca)
         return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
-    int nblk = 1, fin_groups = 1, fin_stride = 0;
+    double* const stat = batch ? s->stat[s->parity] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
+    g.stat = stat; g.sc = DenoiseState::STAT_SC;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], ctx->stream));
     if (s->impl == AIPT_DN_IMPL_VALU) {
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_valu");
-        g.partial = nullptr; g.nblk = 1;
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
-            hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, s->partial);
+            hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, stat);
     } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
         g.a.up = 0; g.b.up = 0;
@@ -1138,11 +1143,6 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         g.w = L.d_w_d2s; g.bias = L.d_bias_d2s;
         g.cout = 4 * L.cout; g.NP = 16; g.d2s = L.cout;
         const TileChoice t = choose_tile(g.H, g.W, 1);
-        nblk = conv_nblk(t, g.H, g.W);
-        if ((size_t)nblk * g.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        g.partial = batch ? s->partial : nullptr;
-        g.nblk = nblk;
-        fin_groups = 4; fin_stride = L.cout;
         const dim3 grid((g.W + 16 * t.mbx - 1) / (16 * t.mbx), (g.H + 4 * t.rw - 1) / (4 * t.rw), 1);
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,1>", t.rw, t.mbx);
         if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, ctx->stream);
@@ -1150,18 +1150,11 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         else launch_mfma<1, 1, 1>(g, grid, ctx->stream);
     } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         const int strips = ((W + 3) / 4) * H;
-        nblk = (strips + 255) / 256;
-        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        g.partial = batch ? s->partial : nullptr;
-        g.nblk = nblk;
+        const int nblk = (strips + 255) / 256;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3>");
         hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, ctx->stream, g);
     } else if (L.cout == 3 && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         const dim3 grid((W + 15) / 16, (H + 15) / 16);
-        nblk = grid.x * grid.y;
-        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        g.partial = batch ? s->partial : nullptr;
-        g.nblk = nblk;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
     } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels()) {
@@ -1174,10 +1167,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
-        nblk = grid.x * grid.y;
-        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        gh.partial = batch ? s->partial : nullptr;
-        gh.nblk = nblk;
+        gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
@@ -1185,10 +1175,6 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
-        nblk = conv_nblk(t, H, W);
-        if ((size_t)nblk * L.cout > s->partial_elems) return fail(ctx, AIPT_E_STATE, "partial buffer too small");
-        g.partial = batch ? s->partial : nullptr;
-        g.nblk = nblk;
         const dim3 grid((W + 16 * t.mbx - 1) / (16 * t.mbx), (H + 4 * t.rw - 1) / (4 * t.rw), L.NB / t.nbb);
         const int key = t.rw * 100 + t.mbx * 10 + t.nbb;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,%d>", t.rw, t.mbx, t.nbb);
@@ -1204,9 +1190,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         }
     }
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], ctx->stream));
-    hipLaunchKernelGGL(bn_finalize, dim3(L.cout), dim3(256), 0, ctx->stream, s->partial, nblk,
-                       1.0 / ((double)H * (double)W), L.d_gamma, L.d_beta, batch ? nullptr : L.d_ab_running, dst.ab,
-                       fin_groups, fin_stride);
+    // how consumers normalise dst: batch statistics from the sums this launch accumulates, or the running-statistics affine
+    if (batch) dst.bn = BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)};
+    else dst.bn = BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};
     AIPT_HIP(ctx, hipGetLastError());
     return AIPT_OK;
 }
@@ -1363,9 +1349,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         int rc = alloc(bytes, (void**)&t.p);
         if (rc) return rc;
         AIPT_HIP(ctx, hipMemsetAsync(t.p, 0, bytes, ctx->stream));   // pad channels of the last quad stay 0
-        rc = alloc(sizeof(float2) * C, (void**)&t.ab);
-        if (rc) return rc;
-        hipLaunchKernelGGL(fill_ab_identity, dim3((C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, C);
+        t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
         return AIPT_OK;
     };
     int rc = mk(s->In, 10, 0);
@@ -1381,17 +1365,9 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         if (!rc) rc = mk(s->D2[k], DEC_CH[k], k - 1);
     }
     if (rc) { free_activations(s); return rc; }
-    // partial sums: cout x (#pixel tiles) for the finest tiling used (4 x 16 pixels)
-    size_t mx = 0;
-    for (int lvl = 0; lvl < 6; lvl++) {
-        const int h = height >> lvl, w = width >> lvl;
-        const size_t tiles = (size_t)((w + 15) / 16) * ((h + 3) / 4) * 2;   // finest granularity: one partial per 32 pixels
-        const int c = lvl < 5 ? ENC_CH[lvl] : 101;
-        if (tiles * c > mx) mx = tiles * c;
-    }
-    rc = alloc(sizeof(float2) * mx, (void**)&s->partial);
+    for (int k = 0; k < 2 && !rc; k++) rc = alloc(sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
     if (rc) { free_activations(s); return rc; }
-    s->partial_elems = mx;
+    s->parity = 0;
     s->H = height; s->W = width;
     s->hidden_valid = false;
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
@@ -1414,20 +1390,33 @@ int aipt_denoise_reset_hidden(aipt_ctx* ctx) {
 int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags) {
     AIPT_CHECK_CTX(ctx);
     DenoiseState* s = state(ctx);
+    return aipt::denoise_run(ctx, d_in10, d_out3, flags, s->H, s->W);
+}
+
+}  // extern "C"
+
+// forward pass; the planar output is cropped to out_h x out_w (aipt_frame drops its padding here)
+int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w) {
+    DenoiseState* s = state(ctx);
     if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise: call aipt_denoise_configure first");
     if (!d_in10 || !d_out3) return fail(ctx, AIPT_E_INVALID, "aipt_denoise: NULL buffer");
+    if (out_h < 1 || out_h > s->H || out_w < 1 || out_w > s->W) return fail(ctx, AIPT_E_INVALID, "aipt_denoise: output %dx%d", out_w, out_h);
     const bool batch = (flags & AIPT_DN_BN_BATCH) != 0;
     const bool carry = (flags & AIPT_DN_HIDDEN_CARRY) != 0 && s->hidden_valid;
     const int H = s->H, W = s->W;
     int li = 0, rc = 0;
+    if (batch) {   // this frame's BN sums go to the other set: the carried hidden states still point into the last one
+        s->parity ^= 1;
+        AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->parity], 0, sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, ctx->stream));
+    }
     Tensor in;
     {   // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94): one small pass re-lays it out as C4
         const size_t hw = (size_t)H * W, n = (size_t)pad4(10) * hw;
         const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
         hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_in10, 10, hw, s->In.p);
     }
-    in = s->In; in.ab = nullptr; in.C = 10; in.slope = 1.0f; in.planar = 0;
+    in = s->In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
     const Tensor* x = &in;
     // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
     for (int i = 0; i < 5; i++) {
@@ -1437,9 +1426,11 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
         Tensor t2 = s->T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
         if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, s->Hid[i], batch, false))) return rc;
         s->Hid[i].slope = SLOPE;
-        const size_t n = (size_t)(pad4(ENC_CH[i]) / 4) * (h / 2) * (w / 2);     // one thread per (channel quad, pooled pixel)
-        const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(pool2_norm, dim3(grid), dim3(256), 0, ctx->stream, s->Hid[i].p, s->Hid[i].ab, SLOPE,
+        const size_t n = (size_t)(h / 2) * (w / 2);                         // one thread per pooled pixel of a channel quad
+        const int quads = pad4(ENC_CH[i]) / 4;
+        int grid = (int)((n + 255) / 256);
+        if (grid * quads > 4096) grid = (4096 + quads - 1) / quads;
+        hipLaunchKernelGGL(pool2_norm, dim3(grid, quads), dim3(256), 0, ctx->stream, s->Hid[i].p, s->Hid[i].bn, SLOPE,
                            ENC_CH[i], h, w, s->P[i].p);
         x = &s->P[i];
     }
@@ -1459,10 +1450,10 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
         prev = &s->D2[k];
     }
     {
-        const size_t n = (size_t)3 * H * W;
-        const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-        hipLaunchKernelGGL(apply_norm, dim3(grid), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].ab, SLOPE, 3,
-                           (size_t)H * W, d_out3);
+        const size_t n = (size_t)out_h * out_w;
+        const int grid = (int)((n + 255) / 256 < 2730 ? (n + 255) / 256 : 2730);
+        hipLaunchKernelGGL(apply_norm, dim3(grid, 3), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].bn, SLOPE, H, W,
+                           d_out3, out_h, out_w);
     }
     AIPT_HIP(ctx, hipGetLastError());
     s->hidden_valid = true;
@@ -1472,6 +1463,8 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
     }
     return li == NLAYERS ? AIPT_OK : fail(ctx, AIPT_E_STATE, "aipt_denoise: ran %d layers", li);
 }
+
+extern "C" {
 
 int aipt_denoise_profile_begin(aipt_ctx* ctx, uint32_t layer_mask, int max_calls) {
     AIPT_CHECK_CTX(ctx);
@@ -1552,9 +1545,9 @@ int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst) {
         AIPT_HIP(ctx, hipMemsetAsync(d_dst, 0, sizeof(float) * t.C * hw, ctx->stream));
         return AIPT_OK;
     }
-    const size_t n = t.C * hw;
-    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(apply_norm, dim3(grid), dim3(256), 0, ctx->stream, t.p, t.ab, t.slope, t.C, hw, d_dst);
+    const int h = s->H >> level, w = s->W >> level;
+    const int grid = (int)((hw + 255) / 256 < 64 ? (hw + 255) / 256 : 64);
+    hipLaunchKernelGGL(apply_norm, dim3(grid, t.C), dim3(256), 0, ctx->stream, t.p, t.bn, t.slope, h, w, d_dst, h, w);
     AIPT_HIP(ctx, hipGetLastError());
     return AIPT_OK;
 }
@@ -1571,7 +1564,7 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
         for (int l = 0; l < 6; l++) {
             Tensor& o = s->Hid[l];
             AIPT_HIP(ctx, hipMemsetAsync(o.p, 0, sizeof(float) * pad4(o.C) * (size_t)(s->H >> l) * (s->W >> l), ctx->stream));
-            hipLaunchKernelGGL(fill_ab_identity, dim3((o.C + 63) / 64), dim3(64), 0, ctx->stream, o.ab, o.C);
+            o.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
             o.slope = 1.0f;
         }
         s->hidden_valid = true;
@@ -1581,7 +1574,7 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
         const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_src, t.C, hw, t.p);
     }
-    hipLaunchKernelGGL(fill_ab_identity, dim3((t.C + 63) / 64), dim3(64), 0, ctx->stream, t.ab, t.C);
+    t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     t.slope = 1.0f;      // already normalised: no LReLU on load
     AIPT_HIP(ctx, hipGetLastError());
     return AIPT_OK;

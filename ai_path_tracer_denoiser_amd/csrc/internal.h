@@ -32,7 +32,6 @@ struct aipt_ctx {
     float* d_gbuf = nullptr;      // [10][fhp][fwp]: the G-buffer of the last aipt_frame (= d_gbufs[front])
     float* d_gbufs[2] = {nullptr, nullptr};
     int front = 0;
-    float* d_out_pad = nullptr;   // [3][fhp][fwp] when cropping is needed
     // aipt_frame_prefetch: the next frame's trace runs on `side` into the back G-buffer while this frame is denoised
     hipStream_t side = nullptr;
     hipEvent_t ev_denoised[2] = {nullptr, nullptr};   // last denoise that read d_gbufs[i] has finished
@@ -76,6 +75,8 @@ inline hipError_t sync_streams(aipt_ctx* ctx) {
     if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
     return e;
 }
+// aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)
+int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w);
 void trace_destroy(aipt_ctx* ctx);
 void denoise_destroy(aipt_ctx* ctx);
 

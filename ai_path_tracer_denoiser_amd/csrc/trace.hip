@@ -31,7 +31,9 @@ struct v3 { float x, y, z; };
 struct DevGeom {          // one primitive; matrices column-major (glm::mat4)
     int type, materialid;
     float inv[16], xf[16], invT[16];
+    float lo[3], hi[3];   // padded world-space box around the primitive (broad phase only, never decides a hit)
 };
+constexpr int MAXG_LDS = 32;   // scenes with up to this many primitives use the per-lane candidate loop
 struct DevFace {          // Face, sceneStructs.h:40
     float v[3][3], n[3][3];
     int materialid;
@@ -156,7 +158,7 @@ __device__ __forceinline__ void det_sincosf(float x, float& s, float& c) {
 // ---------------------------------------------------------------------------------------------- intersections.h
 __device__ __forceinline__ v3 getPointOnRay(v3 o, v3 d, float t) { return vadd(o, vscale(vnormalize(d), t - .0001f)); }
 
-__device__ float boxTest(const DevGeom& g, v3 ro, v3 rd, v3& P, v3& N) {     // :52-94
+__device__ __forceinline__ float boxTest(const DevGeom& g, v3 ro, v3 rd, v3& P, v3& N) {     // :52-94
     const v3 qo = mulMV(g.inv, ro, 1.0f);
     const v3 qd = vnormalize(mulMV(g.inv, rd, 0.0f));
     float tmin = -1e38f, tmax = 1e38f;
@@ -181,7 +183,7 @@ __device__ float boxTest(const DevGeom& g, v3 ro, v3 rd, v3& P, v3& N) {     // 
     return -1.0f;
 }
 
-__device__ float sphereTest(const DevGeom& g, v3 ro, v3 rd, v3& P, v3& N) {  // :106-148
+__device__ __forceinline__ float sphereTest(const DevGeom& g, v3 ro, v3 rd, v3& P, v3& N) {  // :106-148
     const v3 o = mulMV(g.inv, ro, 1.0f);
     const v3 d = vnormalize(mulMV(g.inv, rd, 0.0f));
     const float vDotDirection = vdot(o, d);
@@ -228,6 +230,18 @@ __device__ float triangleTest(const DevFace& f, v3 orig, v3 dir, v3& P, v3& N) {
     const v3 n2 = V(f.n[2][0], f.n[2][1], f.n[2][2]);
     N = vnormalize(vadd(vadd(vscale(n0, bw), vscale(n1, bx)), vscale(n2, by)));
     return bz;
+}
+
+// Broad phase: can the ray touch the primitive's padded world box at all?  Conservative by construction -- the box is
+// padded by 1e-3 of its scale on the host, the slab arithmetic here is good to 3e-7 relative, NaNs answer "maybe" -- so
+// a primitive it rejects is one whose exact test returns "no hit", and skipping that test changes no result bit.
+__device__ __forceinline__ bool maybe_hits(const float* lo, const float* hi, v3 o, v3 inv) {
+    const float t1 = (lo[0] - o.x) * inv.x, t2 = (hi[0] - o.x) * inv.x;
+    const float t3 = (lo[1] - o.y) * inv.y, t4 = (hi[1] - o.y) * inv.y;
+    const float t5 = (lo[2] - o.z) * inv.z, t6 = (hi[2] - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    const float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    return !(tf < 0.0f || tn > tf);
 }
 
 __device__ bool rayAABB(v3 ro, v3 rd, const aipt_aabb& bb) {                  // :175-200
@@ -323,6 +337,7 @@ __device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hi
 template <bool FIRST>
 __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     __shared__ int s_wave[4];
+    __shared__ DevGeom s_geoms[MAXG_LDS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = p.P;
     float* ox = p.st;            float* oy = p.st + (size_t)P;      float* oz = p.st + (size_t)2 * P;
@@ -349,6 +364,14 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
         if (alive) rem = remp[i];
+    }
+
+    // primitives into LDS: the candidate loop below indexes them per lane
+    const bool broad = p.ngeoms <= MAXG_LDS && !(p.flags & AIPT_TRACE_NO_BROAD_PHASE);
+    if (broad) {
+        const int nw = p.ngeoms * (int)(sizeof(DevGeom) / 4);
+        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_geoms)[k] = reinterpret_cast<const int*>(p.geoms)[k];
+        __syncthreads();
     }
 
     bool alive_after = false;
@@ -382,13 +405,33 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
         float t_min = FLT_MAX;
         int materialid = -1;
         v3 hitP = V(0, 0, 0), normal = V(0, 0, 0);
-        for (int gi = 0; gi < p.ngeoms; gi++) {
-            const DevGeom& g = p.geoms[gi];
-            v3 tp, tn;
-            float t = -1.0f;
-            if (g.type == AIPT_GEOM_CUBE) t = boxTest(g, o, d, tp, tn);
-            else if (g.type == AIPT_GEOM_SPHERE) t = sphereTest(g, o, d, tp, tn);
-            if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
+        if (broad) {
+            // broad phase over all primitives (wave-uniform loop, scalar loads), then the exact tests on this lane's
+            // candidates only, in index order (so "the first of equal distances wins" as in the reference's loop): a
+            // wave runs max-over-lanes(candidates) exact tests instead of ngeoms
+            const v3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+            unsigned cand = 0;
+            for (int gi = 0; gi < p.ngeoms; gi++)
+                if (maybe_hits(p.geoms[gi].lo, p.geoms[gi].hi, o, inv)) cand |= 1u << gi;
+            while (cand) {
+                const int gi = __builtin_ctz(cand);
+                cand &= cand - 1;
+                const DevGeom& g = s_geoms[gi];
+                v3 tp, tn;
+                float t = -1.0f;
+                if (g.type == AIPT_GEOM_CUBE) t = boxTest(g, o, d, tp, tn);
+                else if (g.type == AIPT_GEOM_SPHERE) t = sphereTest(g, o, d, tp, tn);
+                if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
+            }
+        } else {
+            for (int gi = 0; gi < p.ngeoms; gi++) {
+                const DevGeom& g = p.geoms[gi];
+                v3 tp, tn;
+                float t = -1.0f;
+                if (g.type == AIPT_GEOM_CUBE) t = boxTest(g, o, d, tp, tn);
+                else if (g.type == AIPT_GEOM_SPHERE) t = sphereTest(g, o, d, tp, tn);
+                if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
+            }
         }
         if (p.nfaces && rayAABB(o, d, p.box)) {                                  // RAY_CULLING true (:23, :258)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
@@ -575,6 +618,24 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
         memcpy(dg[i].inv, geoms[i].inverseTransform, 64);
         memcpy(dg[i].xf, geoms[i].transform, 64);
         memcpy(dg[i].invT, geoms[i].invTranspose, 64);
+        // padded world box of the unit cube [-0.5, 0.5]^3 under the primitive's transform (encloses the unit sphere too)
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        const float* m = geoms[i].transform;                  // column-major
+        for (int c = 0; c < 8; c++) {
+            const double x = (c & 1) ? 0.5 : -0.5, y = (c & 2) ? 0.5 : -0.5, z = (c & 4) ? 0.5 : -0.5;
+            for (int r = 0; r < 3; r++) {
+                const double v = (double)m[0 * 4 + r] * x + (double)m[1 * 4 + r] * y + (double)m[2 * 4 + r] * z + (double)m[3 * 4 + r];
+                if (v < lo[r]) lo[r] = v;
+                if (v > hi[r]) hi[r] = v;
+            }
+        }
+        double scale = 1.0;
+        for (int r = 0; r < 3; r++) { scale = fmax(scale, hi[r] - lo[r]); scale = fmax(scale, fmax(fabs(lo[r]), fabs(hi[r]))); }
+        for (int r = 0; r < 3; r++) {
+            dg[i].lo[r] = (float)(lo[r] - 1e-3 * scale);
+            dg[i].hi[r] = (float)(hi[r] + 1e-3 * scale);
+            if (!(dg[i].lo[r] <= dg[i].hi[r])) { dg[i].lo[r] = -3.0e38f; dg[i].hi[r] = 3.0e38f; }   // NaN/inf transform: never cull
+        }
     }
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_geoms, sizeof(DevGeom) * (ngeoms ? ngeoms : 1)));
     if (ngeoms) AIPT_HIP(ctx, hipMemcpy(s->d_geoms, dg.data(), sizeof(DevGeom) * ngeoms, hipMemcpyHostToDevice));

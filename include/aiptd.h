@@ -121,6 +121,9 @@ int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
 #define AIPT_TRACE_RECORD_MAT0 4u   /* also record the first-hit material id per pixel (integer parity channel) */
 #define AIPT_TRACE_BRUTE_FORCE 8u   /* mesh: test every face in index order like the reference (pathtrace.cu:258-269) instead
                                        of walking the BVH built at upload; same result, for parity checks and timing */
+#define AIPT_TRACE_NO_BROAD_PHASE 16u /* primitives: run the exact box/sphere test of every primitive for every ray like the
+                                       reference (pathtrace.cu:226-245) instead of only on the primitives whose padded
+                                       world box the ray can touch; same result, for parity checks and timing */
 #define AIPT_TRACE_DEFAULT     (AIPT_TRACE_AA | AIPT_TRACE_COMPACT)
 
 /* pathtraceInit (pathtrace.cu:96-129), scene part: copies and re-lays-out the scene on the device.

@@ -111,3 +111,31 @@ def test_multi_spp_accumulation(ctx):
         assert np.array_equal(gbuf.cpu().numpy(), g_ref), f"iteration {it}"
     one, _, _ = sc.pathtrace(iter=1)
     assert not np.array_equal(one[0:3], g_ref[0:3]) and np.array_equal(one[3:10], g_ref[3:10])
+
+
+def test_broad_phase_changes_nothing_on_a_cluttered_scene(ctx):
+    """24 rotated / non-uniformly scaled boxes and spheres (some grazing, some far, some enclosing the camera) inside the
+    Cornell room: the per-lane candidate loop behind the padded-box broad phase must give the reference's exhaustive loop
+    bit for bit -- against the oracle, and against the same kernel with AIPT_TRACE_NO_BROAD_PHASE."""
+    import oracle
+    import ctypes as C
+    sc = oracle.OracleScene.parse(CORNELL, res=(160, 120), depth=5)
+    rng = np.random.default_rng(565)
+    nmat = len(sc.materials)
+    for k in range(24):
+        g = api.Geom()
+        g.type = int(rng.integers(0, 2))                  # AIPT_GEOM_SPHERE = 0, AIPT_GEOM_CUBE = 1
+        g.materialid = int(rng.integers(0, nmat))
+        g.translation[:] = [float(v) for v in rng.uniform([-4.5, 0.5, -4.5], [4.5, 9.5, 4.5])]
+        g.rotation[:] = [float(v) for v in rng.uniform(-180, 180, 3)]
+        scale = rng.uniform(0.05, 3.0, 3) if k % 5 else rng.uniform(6.0, 30.0, 3)   # every 5th is huge (camera inside)
+        g.scale[:] = [float(v) for v in scale]
+        api.lib().aipt_geom_build(C.byref(g))
+        sc.geoms.append(oracle.Geom.from_buffer_copy(bytes(g)))
+    g_ref, n_ref, m_ref = sc.pathtrace()
+    g0, n0, m0 = gpu_trace(ctx, sc, 5)
+    g1, n1, m1 = gpu_trace(ctx, sc, 5, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0 | api.TRACE_NO_BROAD_PHASE)
+    assert np.array_equal(g0, g1) and np.array_equal(m0, m1) and n0.tolist() == n1.tolist()
+    assert np.array_equal(m0, m_ref)
+    assert n0[:len(n_ref)].tolist() == n_ref.tolist()
+    assert np.array_equal(g0, g_ref)

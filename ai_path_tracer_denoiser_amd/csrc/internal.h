@@ -57,14 +57,17 @@ void set_global_error(const char* msg);
 #define AIPT_CHECK_CTX(ctx) \
     do { if (!(ctx)) return AIPT_E_INVALID; } while (0)
 
-// threaded BVH node (bvh.cpp): DFS order; leaf = (first_leaf_face << 3) | count, or -1 for an inner node
+// BVH node (bvh.cpp): DFS order (left child = next node); leaf = (first_leaf_face << 3) | count for a leaf,
+// -(right_child * 4 + split_axis) - 1 for an inner node; skip = first node after the subtree
+constexpr int BVH_LEAF_FACES = 2;
+constexpr int BVH_MAX_DEPTH = 48;    // deepest tree the traversal stack (LDS, depth x 1 KB per workgroup) is allowed to need
 struct BvhNode {
     float lo[3];
     int skip;
     float hi[3];
     int leaf;
 };
-void build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);
+int build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);   // tree depth, -1: too deep
 
 // aipt_trace on an explicit stream; orders itself after the previous trace when that ran on another stream
 int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags, float* d_gbuf,

@@ -43,6 +43,7 @@ struct TraceState {
     DevGeom* d_geoms = nullptr; int ngeoms = 0;
     aipt_material* d_mats = nullptr; int nmats = 0;
     DevFace* d_faces = nullptr; int nfaces = 0;
+    int bvh_depth = 0;
     BvhNode* d_nodes = nullptr; int nnodes = 0;     // threaded BVH over the faces (bvh.cpp)
     DevFace* d_lfaces = nullptr;                    // faces in leaf order
     int* d_lidx = nullptr;                          // their original indices (tie-break + parity with the index-ordered loop)
@@ -334,10 +335,12 @@ __device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hi
 }
 
 // ---------------------------------------------------------------------------------------------- the bounce kernel
-template <bool FIRST>
+// MESH = false drops the triangle path (and its LDS traversal stack) from the instantiation used for primitive-only scenes.
+template <bool FIRST, bool MESH>
 __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     __shared__ int s_wave[4];
     __shared__ DevGeom s_geoms[MAXG_LDS];
+    extern __shared__ int s_stack[];                            // MESH: [tree depth + 1][thread] far children still to visit
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = p.P;
     float* ox = p.st;            float* oy = p.st + (size_t)P;      float* oz = p.st + (size_t)2 * P;
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                 if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
             }
         }
-        if (p.nfaces && rayAABB(o, d, p.box)) {                                  // RAY_CULLING true (:23, :258)
+        if (MESH && p.nfaces && rayAABB(o, d, p.box)) {                                  // RAY_CULLING true (:23, :258)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -442,21 +445,30 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                     if (t > 0.0f && t_min > t) { t_min = t; materialid = p.faces[fi].materialid; hitP = tp; normal = tn; }
                 }
             } else {
-                // threaded BVH: same triangle test on the candidate faces.  The index-ordered loop keeps the FIRST face
+                // BVH, front to back: same triangle test on the candidate faces.  The index-ordered loop keeps the FIRST face
                 // among equal distances and never lets a face replace a primitive at equal distance; best_face
                 // reproduces exactly that, so the result is the brute-force result.
                 const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+                const float dd[3] = {d.x, d.y, d.z};
                 int best_face = -1;
-                int ni = 0;
-                while (ni < p.nnodes) {
+                int sp = 0, ni = 0;
+                while (true) {
                     const BvhNode nd = p.nodes[ni];
                     const float t1 = (nd.lo[0] - o.x) * ix, t2 = (nd.hi[0] - o.x) * ix;
                     const float t3 = (nd.lo[1] - o.y) * iy, t4 = (nd.hi[1] - o.y) * iy;
                     const float t5 = (nd.lo[2] - o.z) * iz, t6 = (nd.hi[2] - o.z) * iz;
                     const float tnear = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
                     const float tfar = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-                    if (tfar < 0.0f || tnear > tfar || tnear > t_min) { ni = nd.skip; continue; }   // NaN -> visit
-                    if (nd.leaf >= 0) {
+                    const bool miss = tfar < 0.0f || tnear > tfar || tnear > t_min;     // NaN -> visit
+                    if (!miss && nd.leaf < 0) {
+                        // inner node: descend into the child on the ray's side of the split first, keep the other one
+                        const int v = -nd.leaf - 1, axis = v & 3, right = v >> 2;
+                        const bool left_first = !(dd[axis] < 0.0f);
+                        s_stack[sp++ * 256 + tid] = left_first ? right : ni + 1;   // depth-bounded by the builder
+                        ni = left_first ? ni + 1 : right;
+                        continue;
+                    }
+                    if (!miss) {
                         const int first = nd.leaf >> 3, cnt = nd.leaf & 7;
                         for (int k = 0; k < cnt; k++) {
                             v3 tp, tn;
@@ -467,10 +479,9 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                                 best_face = fi;
                             }
                         }
-                        ni = nd.skip;
-                    } else {
-                        ni = ni + 1;
                     }
+                    if (sp == 0) break;
+                    ni = s_stack[--sp * 256 + tid];
                 }
             }
         }
@@ -648,7 +659,8 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
     if (nfaces) {
         std::vector<BvhNode> nodes;
         std::vector<int> lidx;
-        build_bvh(faces, nfaces, nodes, lidx);
+        s->bvh_depth = build_bvh(faces, nfaces, nodes, lidx);
+        if (s->bvh_depth < 0) return fail(ctx, AIPT_E_INVALID, "aipt_scene_upload: mesh of %d faces is too deep for the traversal stack", nfaces);
         std::vector<DevFace> lf(lidx.size());
         for (size_t i = 0; i < lidx.size(); i++) memcpy(&lf[i], &faces[lidx[i]], sizeof(DevFace));
         AIPT_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(BvhNode) * nodes.size()));
@@ -739,8 +751,12 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
         p.cnt_out = s->d_cnt[0];
         p.live_in = b == 0 ? nullptr : s->d_live[b & 1];
         p.live_out = s->d_live[(b + 1) & 1];
-        if (b == 0) hipLaunchKernelGGL(trace_bounce<true>, dim3(s->nblk), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(trace_bounce<false>, dim3(s->nblk), dim3(256), 0, st, p);
+        const bool mesh = s->nfaces > 0;
+        const size_t stack_bytes = mesh ? (size_t)(s->bvh_depth + 1) * 256 * sizeof(int) : 0;
+        if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
+        else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(s->nblk), dim3(256), 0, st, p);
+        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
+        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(s->nblk), dim3(256), 0, st, p);
         if (b + 1 < depth) hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
     }
     AIPT_HIP(ctx, hipGetLastError());

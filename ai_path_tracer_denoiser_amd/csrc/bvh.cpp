@@ -3,10 +3,10 @@
 // trace.hip runs the reference's triangle test on the candidate faces and resolves equal hit distances exactly as the
 // index-ordered loop does, so the nearest hit is the brute-force result bit for bit (tests/test_gpu_trace.py).
 //
-// Layout: nodes in depth-first order, 32 bytes each.  An inner node's left child is the next node; its `leaf` field holds
-// -(right_child * 4 + split_axis) - 1, so the traversal can descend into the child nearer to the ray first and keep the
-// other on a short per-lane stack (front-to-back: a hit found early prunes the far subtrees through t_min).  `skip` (first
-// node after the subtree) still allows the stackless fixed-order walk.
+// Layout: 64-byte nodes holding the padded boxes of BOTH children and their references (>= 0: inner node index, < 0:
+// -(first_leaf_face * 8 + count) - 1), depth-first order, root = node 0.  One fetch per inner node tests two boxes; leaves
+// have no node of their own; the traversal descends into the child the ray enters first and keeps the other on a short
+// per-lane stack (front to back: a hit found early prunes far subtrees through t_min).
 // Build: deterministic top-down binned SAH (16 bins, all three axes, centroids); object median along the largest centroid
 // axis wherever the SAH split degenerates, and below a depth limit if the pure SAH tree would be deeper than the kernel's
 // per-lane stack (BVH_MAX_DEPTH).  Leaves of <= 2 faces (measured: 2 beats 4 and 6).  build_bvh returns the tree depth:
@@ -30,6 +30,7 @@ struct BuildCtx {
     float pad;
     int sah_depth = 0;
     int max_depth = 0;
+    int root = 0;
 };
 
 static void face_bounds(const aipt_face& f, float* lo, float* hi) {
@@ -44,9 +45,9 @@ static float half_area(const float* lo, const float* hi) {
     return dx * dy + dy * dz + dz * dx;
 }
 
-static int build_rec(BuildCtx& c, int begin, int end, int depth) {
-    const int me = (int)c.nodes.size();
-    c.nodes.emplace_back();
+// builds the subtree of faces order[begin, end), returns its reference (>= 0: node index, < 0: -(first_leaf_face * 8 +
+// count) - 1) and its padded box
+static int build_rec(BuildCtx& c, int begin, int end, int depth, float* box_lo, float* box_hi) {
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int i = begin; i < end; i++) {
@@ -61,14 +62,18 @@ static int build_rec(BuildCtx& c, int begin, int end, int depth) {
     }
     for (int a = 0; a < 3; a++) {
         const float p = c.pad + 1e-5f * std::max(std::fabs(lo[a]), std::fabs(hi[a]));
-        c.nodes[me].lo[a] = lo[a] - p;
-        c.nodes[me].hi[a] = hi[a] + p;
+        box_lo[a] = lo[a] - p;
+        box_hi[a] = hi[a] + p;
     }
     const int n = end - begin;
     if (n <= BVH_LEAF_FACES) {
-        c.nodes[me].leaf = ((int)c.leaf_faces.size() << 3) | n;
+        const int ref = -((int)c.leaf_faces.size() * 8 + n) - 1;
         for (int i = begin; i < end; i++) c.leaf_faces.push_back(c.order[i]);
-    } else {
+        return ref;
+    }
+    const int me = (int)c.nodes.size();
+    c.nodes.emplace_back();
+    {
         int axis = 0;
         if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
         if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
@@ -134,12 +139,14 @@ static int build_rec(BuildCtx& c, int begin, int end, int depth) {
             std::nth_element(c.order.begin() + begin, c.order.begin() + mid, c.order.begin() + end,
                              [&](int a, int b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
         }
-        build_rec(c, begin, mid, depth + 1);
-        const int right = build_rec(c, mid, end, depth + 1);
-        c.nodes[me].leaf = -(right * 4 + axis) - 1;
+        float l0[3], h0[3], l1[3], h1[3];
+        const int r0 = build_rec(c, begin, mid, depth + 1, l0, h0);
+        const int r1 = build_rec(c, mid, end, depth + 1, l1, h1);
+        BvhNode& nd = c.nodes[me];
+        for (int a = 0; a < 3; a++) { nd.lo0[a] = l0[a]; nd.hi0[a] = h0[a]; nd.lo1[a] = l1[a]; nd.hi1[a] = h1[a]; }
+        nd.ref0 = r0; nd.ref1 = r1; nd.pad0 = nd.pad1 = 0;
         if (depth + 1 > c.max_depth) c.max_depth = depth + 1;
     }
-    c.nodes[me].skip = (int)c.nodes.size();     // first node after this subtree in DFS order
     return me;
 }
 
@@ -167,7 +174,15 @@ int build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, s
         c.nodes.clear(); c.leaf_faces.clear();
         c.nodes.reserve((size_t)nfaces + 16);
         c.leaf_faces.reserve(nfaces);
-        build_rec(c, 0, nfaces, 0);
+        float l[3], h[3];
+        c.root = build_rec(c, 0, nfaces, 0, l, h);
+        if (c.root < 0) {                                      // the whole mesh is one leaf: give it a parent whose other side is empty
+            BvhNode nd;
+            for (int a = 0; a < 3; a++) { nd.lo0[a] = l[a]; nd.hi0[a] = h[a]; nd.lo1[a] = FLT_MAX; nd.hi1[a] = -FLT_MAX; }
+            nd.ref0 = c.root; nd.ref1 = -1; nd.pad0 = nd.pad1 = 0;     // -1: leaf of 0 faces
+            c.nodes.push_back(nd);
+            c.root = 0;
+        }
         if (c.max_depth < BVH_MAX_DEPTH) break;
     }
     if (c.max_depth >= BVH_MAX_DEPTH) return -1;

@@ -57,15 +57,15 @@ void set_global_error(const char* msg);
 #define AIPT_CHECK_CTX(ctx) \
     do { if (!(ctx)) return AIPT_E_INVALID; } while (0)
 
-// BVH node (bvh.cpp): DFS order (left child = next node); leaf = (first_leaf_face << 3) | count for a leaf,
-// -(right_child * 4 + split_axis) - 1 for an inner node; skip = first node after the subtree
+// BVH node (bvh.cpp): the padded boxes and references of both children; ref >= 0: inner node index, ref < 0:
+// -(first_leaf_face * 8 + count) - 1.  Root = node 0.
 constexpr int BVH_LEAF_FACES = 2;
 constexpr int BVH_MAX_DEPTH = 48;    // deepest tree the traversal stack (LDS, depth x 1 KB per workgroup) is allowed to need
 struct BvhNode {
-    float lo[3];
-    int skip;
-    float hi[3];
-    int leaf;
+    float lo0[3]; int ref0;
+    float hi0[3]; int ref1;
+    float lo1[3]; int pad0;
+    float hi1[3]; int pad1;
 };
 int build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);   // tree depth, -1: too deep
 

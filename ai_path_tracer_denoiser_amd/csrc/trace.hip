@@ -449,27 +449,32 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                 // among equal distances and never lets a face replace a primitive at equal distance; best_face
                 // reproduces exactly that, so the result is the brute-force result.
                 const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-                const float dd[3] = {d.x, d.y, d.z};
                 int best_face = -1;
-                int sp = 0, ni = 0;
+                int sp = 0, cur = 0;                           // reference being visited: >= 0 inner node, < 0 leaf
                 while (true) {
-                    const BvhNode nd = p.nodes[ni];
-                    const float t1 = (nd.lo[0] - o.x) * ix, t2 = (nd.hi[0] - o.x) * ix;
-                    const float t3 = (nd.lo[1] - o.y) * iy, t4 = (nd.hi[1] - o.y) * iy;
-                    const float t5 = (nd.lo[2] - o.z) * iz, t6 = (nd.hi[2] - o.z) * iz;
-                    const float tnear = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-                    const float tfar = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-                    const bool miss = tfar < 0.0f || tnear > tfar || tnear > t_min;     // NaN -> visit
-                    if (!miss && nd.leaf < 0) {
-                        // inner node: descend into the child on the ray's side of the split first, keep the other one
-                        const int v = -nd.leaf - 1, axis = v & 3, right = v >> 2;
-                        const bool left_first = !(dd[axis] < 0.0f);
-                        s_stack[sp++ * 256 + tid] = left_first ? right : ni + 1;   // depth-bounded by the builder
-                        ni = left_first ? ni + 1 : right;
-                        continue;
-                    }
-                    if (!miss) {
-                        const int first = nd.leaf >> 3, cnt = nd.leaf & 7;
+                    if (cur >= 0) {
+                        const BvhNode nd = p.nodes[cur];
+                        const float a1 = (nd.lo0[0] - o.x) * ix, a2 = (nd.hi0[0] - o.x) * ix;
+                        const float a3 = (nd.lo0[1] - o.y) * iy, a4 = (nd.hi0[1] - o.y) * iy;
+                        const float a5 = (nd.lo0[2] - o.z) * iz, a6 = (nd.hi0[2] - o.z) * iz;
+                        const float b1 = (nd.lo1[0] - o.x) * ix, b2 = (nd.hi1[0] - o.x) * ix;
+                        const float b3 = (nd.lo1[1] - o.y) * iy, b4 = (nd.hi1[1] - o.y) * iy;
+                        const float b5 = (nd.lo1[2] - o.z) * iz, b6 = (nd.hi1[2] - o.z) * iz;
+                        const float n0 = fmaxf(fmaxf(fminf(a1, a2), fminf(a3, a4)), fminf(a5, a6));
+                        const float f0 = fminf(fminf(fmaxf(a1, a2), fmaxf(a3, a4)), fmaxf(a5, a6));
+                        const float n1 = fmaxf(fmaxf(fminf(b1, b2), fminf(b3, b4)), fminf(b5, b6));
+                        const float f1 = fminf(fminf(fmaxf(b1, b2), fmaxf(b3, b4)), fmaxf(b5, b6));
+                        const bool h0 = !(f0 < 0.0f || n0 > f0 || n0 > t_min);      // NaN -> visit
+                        const bool h1 = !(f1 < 0.0f || n1 > f1 || n1 > t_min);
+                        if (h0 && h1) {                                            // nearer child first, the other one waits
+                            const bool first0 = n0 <= n1;
+                            s_stack[sp++ * 256 + tid] = first0 ? nd.ref1 : nd.ref0;   // depth-bounded by the builder
+                            cur = first0 ? nd.ref0 : nd.ref1;
+                            continue;
+                        }
+                        if (h0 || h1) { cur = h0 ? nd.ref0 : nd.ref1; continue; }
+                    } else {
+                        const int v = -cur - 1, first = v >> 3, cnt = v & 7;
                         for (int k = 0; k < cnt; k++) {
                             v3 tp, tn;
                             const float t = triangleTest(p.lfaces[first + k], o, d, tp, tn);
@@ -481,7 +486,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                         }
                     }
                     if (sp == 0) break;
-                    ni = s_stack[--sp * 256 + tid];
+                    cur = s_stack[--sp * 256 + tid];
                 }
             }
         }

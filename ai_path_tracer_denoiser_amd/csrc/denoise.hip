@@ -934,17 +934,23 @@ __global__ __launch_bounds__(256) void pool2_norm(const float* raw, const BnRef 
 }
 
 // planar out[c][y][x] = lrelu(a*raw+b) of a C4 tensor [.][H][W][4], cropped to oh x ow (network output: the frame's
-// padding is dropped here; hidden-state export: oh = H, ow = W).  blockIdx.y = channel.
-__global__ __launch_bounds__(256) void apply_norm(const float* raw, const BnRef bn, float slope, int H, int W, float* out,
-                                                  int oh, int ow) {
-    const int c = blockIdx.y;
-    const float2 f = bn_ab(bn, c);
-    const float* src = raw + (size_t)(c >> 2) * H * W * 4 + (c & 3);
-    float* dst = out + (size_t)c * oh * ow;
+// padding is dropped here; hidden-state export: oh = H, ow = W).  blockIdx.y = channel quad: one 16-byte load per pixel,
+// up to four coalesced plane stores.
+__global__ __launch_bounds__(256) void apply_norm(const float* raw, const BnRef bn, float slope, int C, int H, int W,
+                                                  float* out, int oh, int ow) {
+    const int q = blockIdx.y;
+    float2 f[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) f[k] = q * 4 + k < C ? bn_ab(bn, q * 4 + k) : make_float2(0.0f, 0.0f);
+    const float4* src = reinterpret_cast<const float4*>(raw) + (size_t)q * H * W;
     const size_t n = (size_t)oh * ow;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / ow), x = (int)(i - (size_t)y * ow);
-        dst[i] = lrelu(fmaf(f.x, src[((size_t)y * W + x) * 4], f.y), slope);
+        const float4 r = src[(size_t)y * W + x];
+        const float e[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (q * 4 + k < C) out[(size_t)(q * 4 + k) * n + i] = lrelu(fmaf(f[k].x, e[k], f[k].y), slope);
     }
 }
 
@@ -1451,8 +1457,8 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     }
     {
         const size_t n = (size_t)out_h * out_w;
-        const int grid = (int)((n + 255) / 256 < 2730 ? (n + 255) / 256 : 2730);
-        hipLaunchKernelGGL(apply_norm, dim3(grid, 3), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].bn, SLOPE, H, W,
+        const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        hipLaunchKernelGGL(apply_norm, dim3(grid, 1), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].bn, SLOPE, 3, H, W,
                            d_out3, out_h, out_w);
     }
     AIPT_HIP(ctx, hipGetLastError());
@@ -1547,7 +1553,7 @@ int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst) {
     }
     const int h = s->H >> level, w = s->W >> level;
     const int grid = (int)((hw + 255) / 256 < 64 ? (hw + 255) / 256 : 64);
-    hipLaunchKernelGGL(apply_norm, dim3(grid, t.C), dim3(256), 0, ctx->stream, t.p, t.bn, t.slope, h, w, d_dst, h, w);
+    hipLaunchKernelGGL(apply_norm, dim3(grid, pad4(t.C) / 4), dim3(256), 0, ctx->stream, t.p, t.bn, t.slope, t.C, h, w, d_dst, h, w);
     AIPT_HIP(ctx, hipGetLastError());
     return AIPT_OK;
 }

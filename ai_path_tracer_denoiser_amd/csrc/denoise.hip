@@ -445,6 +445,7 @@ struct ConvArgsH {
     int out_lrelu;
     double* stat;                  // BN sums of the output (nullptr: not wanted), [NSLOT][sc][2]
     int sc;
+    int d2s;                       // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to pixel (2y+a, 2x+b), channel j
     int tiles_x, tiles_y, groups;
 };
 
@@ -658,6 +659,29 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 s1 += m; s2 = fmaf(m, m, s2);
             }
         }
+        if (g.d2s) {
+            // upsample+conv as a half-resolution conv: the 4 * d2s (<= 16) virtual channels of a pixel are the d2s real
+            // channels of its four full-resolution children.  Through LDS (this wave's own 2 KB; the loop's last barrier
+            // has passed): [pixel][16 channels], then one 16-byte C4 store per (pixel, child).
+            float* buf = reinterpret_cast<float*>(smem) + 1024 + (wave * RW + r) * 32 * 16;    // behind the BN reduction slots
+            if (li < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) buf[(8 * (k >> 2) + 4 * lg + (k & 3)) * 16 + li] = t[k];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int o = lane + 64 * h, px = o >> 2, par = o & 3;
+                const float* c = buf + px * 16 + par * g.d2s;
+                const int x = tx0 + px;
+                if (y < H && x < W)
+                    *reinterpret_cast<f32x4*>(g.out + (((size_t)(2 * y + (par >> 1)) * (2 * W)) + 2 * x + (par & 1)) * 4) =
+                        f32x4{c[0], g.d2s > 1 ? c[1] : 0.0f, g.d2s > 2 ? c[2] : 0.0f, g.d2s > 3 ? c[3] : 0.0f};
+            }
+            continue;
+        }
         float* orow = g.out + (((size_t)(j >> 2) * H + y) * W + tx0 + 4 * lg + (lane & 3)) * 4;
 #pragma unroll
         for (int qq = 0; qq < 4; qq++) {
@@ -677,7 +701,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             if (jj < g.cout) {
                 float2 t = red[tid];
                 for (int w = 1; w < NWV; w++) { t.x += red[w * 32 + tid].x; t.y += red[w * 32 + tid].y; }
-                bn_accumulate(g.stat, g.sc, jj, t.x, t.y);
+                bn_accumulate(g.stat, g.sc, g.d2s ? jj % g.d2s : jj, t.x, t.y);   // d2s: a channel's four children share its sums
             }
         }
     }
@@ -978,6 +1002,8 @@ struct LayerW {
     int coutp32 = 0, nchunks16 = 0, ca16 = 0;
     unsigned char* d_wsplit = nullptr;
     float* d_bias32 = nullptr;
+    unsigned char* d_wsplit_d2s = nullptr;   // the same layout for the depth-to-space form of dec1.c1 (12 virtual outputs in one group)
+    float* d_bias32_d2s = nullptr;
 };
 
 struct Tensor {
@@ -1045,7 +1071,7 @@ static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
         hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_bias32);
-        hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s);
+        hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s); hipFree(l.d_wsplit_d2s); hipFree(l.d_bias32_d2s);
         l = LayerW();
     }
     s->have_weights = false;
@@ -1142,6 +1168,21 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, stat);
+    } else if (L.d_wsplit_d2s && upA && g.b.C && s->impl == AIPT_DN_IMPL_MFMA_F16X3 && 4 * L.cout <= 16) {
+        // upsample + conv with 3 outputs on the split-fp16 kernel: half-resolution conv, 12 virtual channels, depth-to-space store
+        ConvArgsH gh;
+        gh.a = g.a; gh.b = g.b; gh.a.up = 0; gh.b.up = 0;
+        gh.H = H / 2; gh.W = W / 2;
+        gh.wsplit = L.d_wsplit_d2s; gh.bias = L.d_bias32_d2s;
+        gh.cout = 4 * L.cout; gh.coutp = 32;
+        gh.nchunks = L.nchunks16; gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
+        gh.out = dst.p; gh.out_lrelu = out_lrelu;
+        gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
+        gh.d2s = L.cout;
+        const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
+        gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
+        hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, ctx->stream, gh);
     } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
         g.a.up = 0; g.b.up = 0;
@@ -1174,6 +1215,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
+        gh.d2s = 0;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
@@ -1290,6 +1332,38 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias_d2s, vnp * 4));
             AIPT_HIP(ctx, hipMemcpy(L.d_w_d2s, wv.data(), wv.size() * 4, hipMemcpyHostToDevice));
             AIPT_HIP(ctx, hipMemcpy(L.d_bias_d2s, bv.data(), vnp * 4, hipMemcpyHostToDevice));
+            // the same virtual-channel weights, split and tiled for conv3x3_f16x3 (one group of 32, K16 concat space)
+            const int cbv = L.cin - L.ca, nch = pad16(L.ca) / KH + pad16(cbv) / KH;
+            std::vector<float> wf((size_t)vco * (nch * KH) * 9, 0.0f);                 // [v][kc][tap]
+            for (int par = 0; par < 4; par++) {
+                const int a = par >> 1, bb = par & 1;
+                for (int j = 0; j < L.cout; j++)
+                    for (int c = 0; c < L.cin; c++) {
+                        const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
+                        for (int ky = 0; ky < 3; ky++)
+                            for (int kx = 0; kx < 3; kx++) {
+                                const int dy = (a + ky + 1) / 2 - 1, dx = (bb + kx + 1) / 2 - 1;
+                                wf[((size_t)(par * L.cout + j) * (nch * KH) + kc) * 9 + (dy + 1) * 3 + (dx + 1)] +=
+                                    w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx];
+                            }
+                    }
+            }
+            std::vector<_Float16> ws((size_t)nch * (WSLAB / 2), (_Float16)0.0f);
+            for (int v = 0; v < vco; v++)
+                for (int kc = 0; kc < nch * KH; kc++)
+                    for (int t = 0; t < 9; t++) {
+                        const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t];
+                        const _Float16 h = (_Float16)x;
+                        const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v) * KH + (kc % KH);
+                        ws[o] = h;
+                        ws[o + 9 * 32 * KH] = (_Float16)((x - (float)h) * 2048.0f);
+                    }
+            std::vector<float> b32v(32, 0.0f);
+            for (int v = 0; v < vco; v++) b32v[v] = bv[v];
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit_d2s, ws.size() * 2));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias32_d2s, 32 * 4));
+            AIPT_HIP(ctx, hipMemcpy(L.d_wsplit_d2s, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMemcpy(L.d_bias32_d2s, b32v.data(), 32 * 4, hipMemcpyHostToDevice));
         }
         {   // split-fp16 weights, pre-tiled per (output-channel group, chunk) slab
             const int cb = L.cin - L.ca;

@@ -486,7 +486,9 @@ __device__ __forceinline__ void quad_transpose_dpp(float (&r)[4], int lane) {
     }
 }
 
-template <int RW, int NWV>
+// PLANAR: source a is a planar tensor [C][h][w] (the network input = the G-buffer contract): four 4-byte loads per staging
+// unit instead of one 16-byte load, no separate layout pass over the input.
+template <int RW, int NWV, bool PLANAR = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
     using Cfg = ConvCfgH<RW, NWV>;
     constexpr int NT = Cfg::NT, TPQ = Cfg::TPQ;
@@ -565,8 +567,22 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const unsigned char* base = reinterpret_cast<const unsigned char*>(s.p) + (size_t)cl * 4 * plane16;
         const int nq = (pad4(s.C) >> 2) - cl * 4;                          // real quads in this chunk (>= 1)
         const unsigned qo = q < nq ? q_off : 0u;                           // pad quads re-read quad 0 (their a,b are 0)
+        if (PLANAR) {
+            const float* pl = g.a.p;
+            const size_t plane = plane16 >> 4;                              // elements of one channel plane
 #pragma unroll
-        for (int j = 0; j < NU; j++) pa[j] = *reinterpret_cast<const f32x4*>(base + (u_off[j] + qo));
+            for (int j = 0; j < NU; j++) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    int ch = chunk * KH + q * 4 + t;
+                    ch = ch < g.a.C ? ch : g.a.C - 1;                       // pad channels: any finite value (their a, b are 0)
+                    pa[j][t] = pl[(size_t)ch * plane + (u_off[j] >> 4)];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NU; j++) pa[j] = *reinterpret_cast<const f32x4*>(base + (u_off[j] + qo));
+        }
         const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
 #pragma unroll
         for (int j = 0; j < NWP; j++)
@@ -1219,7 +1235,10 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
-        if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
+        if (gh.a.planar) {
+            if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
+            hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
+        } else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
         else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
@@ -1491,12 +1510,17 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
         AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->parity], 0, sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, ctx->stream));
     }
     Tensor in;
-    {   // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94): one small pass re-lays it out as C4
+    // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94).  The split-fp16 conv reads it as it is; the other
+    // implementations get a C4 copy first.
+    in = s->In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
+    const bool direct = s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels();
+    if (direct) {
+        in.p = const_cast<float*>(d_in10); in.planar = 1;
+    } else {
         const size_t hw = (size_t)H * W, n = (size_t)pad4(10) * hw;
         const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
         hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_in10, 10, hw, s->In.p);
     }
-    in = s->In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
     const Tensor* x = &in;
     // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
     for (int i = 0; i < 5; i++) {

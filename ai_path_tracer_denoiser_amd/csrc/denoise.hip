@@ -4,19 +4,21 @@
 // training/recurrent_autoencoder_model.py:8-142 (28 x conv3x3+bias, 28 x BatchNorm2d, LeakyReLU(0.1), 5 x MaxPool2d(2),
 // 5 x nearest Upsample x2, skip concats, 6 recurrent hidden states).
 //
-// Data layout in HBM: every activation is fp32 in the channel-quad interleaved "C4" layout [C/4][h][w][4] (see ConvSrc;
-// the planar G-buffer input is re-laid-out once per frame by planar_to_c4).
+// Data layout in HBM: every activation is fp32 in the channel-quad interleaved "C4" layout [C/4][h][w][4] (see ConvSrc);
+// the planar G-buffer input is read as it is by the first conv.
 // Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and
-// accumulates per-channel sum / sum-of-squares partials in its epilogue; a tiny finalize kernel turns them into a
-// per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a).  The CONSUMER applies x -> lrelu(a*x+b) while it
-// stages its input tile into LDS, so BatchNorm, LeakyReLU, channel concat (two source pointers) and nearest upsample
-// (source indexed at (y>>1, x>>1)) never touch HBM as separate passes.  Zero padding is applied in the normalised
-// domain (out-of-image taps load 0, not f(0)).  MaxPool needs normalised values, so one small pool kernel per encoder
-// level materialises the pooled, normalised skip tensor (quarter size).
+// adds its per-channel sum / sum of squares to the layer's statistics table (fp64 atomics, 8 replicas); the CONSUMER turns
+// them into the per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a) in its prologue (BnRef / bn_ab) and
+// applies x -> lrelu(a*x+b) while it stages its input tile into LDS, so BatchNorm, LeakyReLU, channel concat (two source
+// pointers) and nearest upsample (source indexed at (y>>1, x>>1)) never touch HBM as separate passes and there is no
+// launch between two convs.  Zero padding is applied in the normalised domain (out-of-image taps load 0, not f(0)).
+// MaxPool needs normalised values, so one small pool kernel per encoder level materialises the pooled, normalised skip
+// tensor (quarter size).
 //
-// Hot kernel: conv3x3_mfma -- implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation; M = 16
-// consecutive pixels of a row, N = 16 output channels, K = 4 input channels of one filter tap), LDS-staged halo tile
-// and weight slab per 8-channel chunk.  Bound: fp32 MFMA peak (157.3 TFLOP/s); see DESIGN.md.
+// Kernels: conv3x3_f16x3 -- implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into fp16 hi/lo pairs (the
+// default on levels >= 92 x 160, the depth-to-space form of dec1.c1 and the planar-input first conv included);
+// conv3x3_mfma -- the same GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation; the deep levels, and
+// everything under AIPT_DN_IMPL_MFMA); conv3x3_quad -- the 3 -> 3 output layer.  Rooflines and measurements: DESIGN.md.
 #include "internal.h"
 
 #include <cmath>

@@ -78,3 +78,24 @@ def test_state_dict_exporter_roundtrip():
     assert arch.blob_from_state_dict(sd) == arch.pack_blob(p)
     names = [t[1] for t in arch.layer_table()]
     assert names[0] == "encoder1.0.layer1.0" and names[4] == "encoder2.0.layer2.0" and names[-1] == "decoder1.layer1.4"
+
+
+def test_torch_restatement_agrees_with_the_c_oracle():
+    """oracle/torch_denoise.py (the PyTorch-CPU leg of bench.py's cpu_baseline) against the C restatement: two independent
+    restatements of recurrent_autoencoder_model.py, all BN / hidden modes, two frames each."""
+    import oracle
+    from oracle.torch_denoise import TorchDenoiser
+    from ai_path_tracer_denoiser_amd import synth
+    blob = synth.make_blob(3)
+    H, W = 64, 96
+    rng = np.random.default_rng(0)
+    orc = oracle.DenoiseOracle(blob, H, W)
+    td = TorchDenoiser(blob)
+    for bn_batch, carry in [(True, False), (True, True), (False, True), (False, False)]:
+        orc.reset_hidden()
+        td.hidden = None
+        for k in range(2):
+            x = rng.random((10, H, W), dtype=np.float32)
+            a = orc.forward(x, bn_batch, carry and k > 0)
+            b = td.forward(x, bn_batch, carry and k > 0)
+            assert np.abs(a - b).max() < 1e-3, (bn_batch, carry, k, float(np.abs(a - b).max()))

@@ -74,3 +74,42 @@ def test_prefetch_pipeline_is_bit_identical():
     a, b = run(False), run(True)
     for k, (x, y) in enumerate(zip(a, b)):
         assert np.array_equal(x, y), f"frame {k} differs under prefetch"
+
+
+def test_frame_sharding_is_equivalent_to_one_rank_with_resets():
+    """rank r renders a contiguous chunk of the frame sequence and starts it from a zero hidden state.  Two
+    'ranks' (two contexts on this GPU, chunks of 3 frames, cameras from dist.frame_shard / pan_phi) must produce the frames
+    one context produces when it resets the hidden state at the chunk boundary -- byte for byte."""
+    import torch
+    from ai_path_tracer_denoiser_amd import dist as adist
+    W, H, depth, per = 96, 64, 4, 3
+    sc = api.Scene(CORNELL, res=(W, H), depth=depth)
+    blob = synth.make_blob(11)
+
+    def cam(g):
+        c = api.Camera.from_buffer_copy(bytes(sc.camera))
+        api.lib().aipt_camera_orbit(c, sc.zoom, adist.pan_phi(sc.phi, g), sc.theta)
+        return c
+
+    def make_ctx():
+        ctx = api.Context(0)
+        ctx.pathtrace_init(sc.geoms, sc.materials, sc.faces, None)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        return ctx
+
+    out = torch.empty(3, H, W, device="cuda")
+    sharded = {}
+    for rank in range(2):
+        ctx = make_ctx()
+        for k, g in enumerate(adist.frame_shard(rank, 2, per)):
+            ctx.frame(cam(g), 1, depth, out, bn_batch=True, carry=k > 0)
+            ctx.sync()
+            sharded[g] = out.cpu().numpy().copy()
+        ctx.close()
+    ctx = make_ctx()
+    for g in range(2 * per):
+        ctx.frame(cam(g), 1, depth, out, bn_batch=True, carry=g % per != 0)
+        ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), sharded[g]), f"frame {g}"
+    ctx.close()

@@ -58,12 +58,16 @@ struct BnRef {
 };
 __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
     if (r.stat) {
+        // all replicas are loaded before the first add: written as one accumulate loop, hipcc waits for each 16-byte load
+        // before issuing the next (8 serial L2 round trips, 7 k cycles per consumer workgroup)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* st = reinterpret_cast<const d2*>(r.stat) + c;
+        d2 v[NSLOT];
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) v[k] = __builtin_nontemporal_load(st + (size_t)k * r.sc);
         double sx = 0.0, sxx = 0.0;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) {
-            sx += r.stat[((size_t)k * r.sc + c) * 2];
-            sxx += r.stat[((size_t)k * r.sc + c) * 2 + 1];
-        }
+        for (int k = 0; k < NSLOT; k++) { sx += v[k][0]; sxx += v[k][1]; }
         const double mean = sx * r.inv_n;
         double var = sxx * r.inv_n - mean * mean;          // biased variance, as torch normalises with
         if (var < 0) var = 0;

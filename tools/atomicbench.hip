@@ -7,15 +7,16 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __global__ __launch_bounds__(512) void k(const float4* in, float4* out, double* acc, int slots, int stride, int do_atomics) {
+    // do_atomics == 2: the replicas of a channel share one 128-byte line ([channel][slot][2])
     const size_t base = (size_t)blockIdx.x * 6144;              // 6144 float4 = 96 KB per workgroup
     float4 s = make_float4(0, 0, 0, 0);
     for (int i = threadIdx.x; i < 6144; i += 512) { const float4 v = in[base + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     for (int i = threadIdx.x; i < 2048; i += 512) out[(size_t)blockIdx.x * 2048 + i] = s;
     if (do_atomics && threadIdx.x < 32) {
         const int slot = blockIdx.x % slots;
-        double* a = acc + ((size_t)slot * 32 + threadIdx.x) * 2 * stride;
+        double* a = do_atomics == 2 ? acc + ((size_t)threadIdx.x * slots + slot) * 2 : acc + ((size_t)slot * 32 + threadIdx.x) * 2 * stride;
         atomicAdd(a, (double)s.x);
-        atomicAdd(a + stride, (double)s.y);
+        atomicAdd(a + (do_atomics == 2 ? 1 : stride), (double)s.y);
     }
 }
 
@@ -29,7 +30,7 @@ int main() {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     struct { int atom, slots, stride; const char* name; } cfg[] = {
         {0, 1, 1, "no atomics"}, {1, 1, 1, "1 slot compact"}, {1, 8, 1, "8 slots compact"}, {1, 32, 1, "32 slots compact"},
-        {1, 8, 16, "8 slots, line each"}, {1, 1, 16, "1 slot, line each"}};
+        {1, 8, 16, "8 slots, line each"}, {1, 1, 16, "1 slot, line each"}, {2, 8, 1, "8 slots in the channel's line"}, {2, 4, 1, "4 slots in the channel's line"}, {1, 4, 1, "4 slots compact"}, {1, 2, 1, "2 slots compact"}};
     for (auto& c : cfg) {
         float best = 1e9f;
         for (int rep = 0; rep < 6; rep++) {

@@ -1064,6 +1064,11 @@ struct DenoiseState {
 
 // smallest level (in pixels) that runs on the split-fp16 kernel; below it the f32-MFMA kernels with their smaller tiles
 // fill the chip better (AIPT_F16_MINPIX overrides, for tuning)
+// smallest level that runs on the split-fp16 kernel at all (with 2- or 4-row tiles below f16_min_pixels)
+static long f16_small_min_pixels() {
+    static const long v = getenv("AIPT_F16_SMALL_MINPIX") ? atol(getenv("AIPT_F16_SMALL_MINPIX")) : 0;
+    return v;
+}
 static long f16_min_pixels() {
     static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
     return v;
@@ -1226,7 +1231,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const dim3 grid((W + 15) / 16, (H + 15) / 16);
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels()) {
+    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_small_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
@@ -1235,7 +1240,11 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.nchunks = g.b.C ? L.nchunks16 : L.ca16;                 // an all-zero second source (hidden reset) is skipped
         gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
-        const dim3 grid((W + 31) / 32, (H + 7) / 8, L.coutp32 / 32);
+        // tile rows = waves per workgroup: 8 on the big levels; the small levels (< f16_min_pixels) have too few 8 x 32 tiles
+        // to fill 256 CUs and run 2- or 4-row tiles
+        static const int small_rows = getenv("AIPT_F16_SMALL_ROWS") ? atoi(getenv("AIPT_F16_SMALL_ROWS")) : 4;
+        const int rows = (long)H * W >= f16_min_pixels() ? 8 : small_rows;
+        const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
@@ -1244,7 +1253,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
             hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
-        } else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
+        } else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, ctx->stream, gh);
+        else if (rows == 4) hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
+        else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
         else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);

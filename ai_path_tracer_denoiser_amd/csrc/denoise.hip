@@ -1208,7 +1208,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = L.cout;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,8,false>");
         hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, ctx->stream, gh);
     } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
@@ -1247,7 +1247,8 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3");
+        // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,%d,%s>", gh.a.planar ? 8 : rows, gh.a.planar ? "true" : "false");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
         if (gh.a.planar) {

@@ -3,7 +3,7 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline-events
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline-events
-    python tools/pmc_summarize.py gpurun_out/pmc_f/p_counter_collection.csv gpurun_out/pmc_w/p_counter_collection.csv conv3x3_f16x3
+    python tools/pmc_summarize.py gpurun_out/pmc_f/p_counter_collection.csv gpurun_out/pmc_w/p_counter_collection.csv 'conv3x3_f16x3<1,8,false>'
 
 Units and corrections as MI355X_MICROARCH.md prescribes: both counters are in KiB; FETCH_SIZE is doubled on gfx950 (wide
 coalesced reads are reported at half); separate passes because the two counters do not share a pass reliably."""
@@ -16,7 +16,7 @@ import sys
 def per_launch(path, counter, kernel):
     vals = []
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].replace("void aipt::", "").split("(")[0].split("<")[0]
+        name = r["Kernel_Name"].replace("void aipt::", "").split("(")[0].replace(" ", "")
         if name == kernel and r["Counter_Name"] == counter:
             vals.append(float(r["Counter_Value"]))
     if not vals:

@@ -494,10 +494,13 @@ __device__ __forceinline__ void quad_transpose_dpp(float (&r)[4], int lane) {
 
 // PLANAR: source a is a planar tensor [C][h][w] (the network input = the G-buffer contract): four 4-byte loads per staging
 // unit instead of one 16-byte load, no separate layout pass over the input.
-template <int RW, int NWV, bool PLANAR = false>
+// W16: fp16 conv weights (BASELINE configs[4], AIPT_DN_IMPL_MFMA_F16W): the weights are the fp16 roundings the hi half
+// of the slab already holds, so the lo half is neither staged nor multiplied (2 MFMAs per product, half the weight traffic).
+template <int RW, int NWV, bool PLANAR = false, bool W16 = false>
 __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
     using Cfg = ConvCfgH<RW, NWV>;
     constexpr int NT = Cfg::NT, TPQ = Cfg::TPQ;
+    constexpr int WP = W16 ? WSLAB / 32 : WSLAB / 16;          // 16-byte weight pieces of a chunk that are staged
     constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU, NWP = Cfg::NWP;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES + 8 * Cfg::MAXC];
     unsigned char* Ahi = smem;
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
 #pragma unroll
         for (int j = 0; j < NWP; j++)
-            if ((j + 1) * NT <= WSLAB / 16 || tid + j * NT < WSLAB / 16)  // wave-uniform (WSLAB/16 is a multiple of 64)
+            if ((j + 1) * NT <= WP || tid + j * NT < WP)      // wave-uniform (WP is a multiple of 64)
                 pw[j] = *reinterpret_cast<const u32x4*>(wsrc + j * NT * 16);
     };
     auto stash = [&](int chunk) {
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         }
 #pragma unroll
         for (int j = 0; j < NWP; j++)
-            if ((j + 1) * NT <= WSLAB / 16 || tid + j * NT < WSLAB / 16)
+            if ((j + 1) * NT <= WP || tid + j * NT < WP)
                 *reinterpret_cast<u32x4*>(Bhi + w_lds[j]) = pw[j];
     };
 
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
                     acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
-                    acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
+                    if (!W16) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
                     acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc1[r], 0, 0, 0);
                 }
             }
@@ -1017,6 +1020,8 @@ struct LayerW {
     int cin = 0, cout = 0, NB = 0, NP = 0, nchunks = 0;
     int ca = 0, pcin = 0;   // channels of the first concat source; padded-concat channel count (pad4(ca) + pad4(cin - ca))
     float *d_w = nullptr, *d_w_raw = nullptr, *d_bias = nullptr, *d_gamma = nullptr, *d_beta = nullptr;
+    float* d_w_raw16 = nullptr;              // the weights rounded to fp16 (AIPT_DN_IMPL_MFMA_F16W), for the direct-conv kernels
+    unsigned char* d_wsplit_d2s16 = nullptr; // depth-to-space weights built from the fp16-rounded taps
     float2* d_ab_running = nullptr;
     float *d_w_d2s = nullptr, *d_bias_d2s = nullptr;   // upsample+conv as a half-resolution conv with 4*cout virtual channels
     // split-fp16 copy of the weights for conv3x3_f16x3: [coutp32/32][nchunks16][hi | lo*2^11][9][32][16] halfs over the
@@ -1069,6 +1074,7 @@ static long f16_small_min_pixels() {
     static const long v = getenv("AIPT_F16_SMALL_MINPIX") ? atol(getenv("AIPT_F16_SMALL_MINPIX")) : 0;
     return v;
 }
+static inline bool impl_is_f16(int impl) { return impl == AIPT_DN_IMPL_MFMA_F16X3 || impl == AIPT_DN_IMPL_MFMA_F16W; }
 static long f16_min_pixels() {
     static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
     return v;
@@ -1096,6 +1102,7 @@ static void build_table(int* cin, int* cout) {
 
 static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
+        hipFree(l.d_w_raw16); hipFree(l.d_wsplit_d2s16);
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
         hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_bias32);
         hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s); hipFree(l.d_wsplit_d2s); hipFree(l.d_bias32_d2s);
@@ -1176,7 +1183,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     if (B && use_b) g.b = ConvSrc{B->p, B->bn, B->C, upB, B->slope, B->planar};
     else g.b = ConvSrc{nullptr, BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0}, 0, 0, 1.0f, 0};
     g.H = H; g.W = W;
-    g.w = L.d_w; g.w_raw = L.d_w_raw; g.bias = L.d_bias;
+    g.w = L.d_w; g.w_raw = s->impl == AIPT_DN_IMPL_MFMA_F16W ? L.d_w_raw16 : L.d_w_raw; g.bias = L.d_bias;
     g.cin = L.cin; g.cout = L.cout; g.NP = L.NP;
     g.nchunks = (pad4(g.a.C) + pad4(g.b.C) + KC - 1) / KC;      // padded-concat channel space
     g.out = dst.p; g.out_lrelu = out_lrelu;
@@ -1195,12 +1202,14 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, stat);
-    } else if (L.d_wsplit_d2s && upA && g.b.C && s->impl == AIPT_DN_IMPL_MFMA_F16X3 && 4 * L.cout <= 16) {
+    } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16) {
         // upsample + conv with 3 outputs on the split-fp16 kernel: half-resolution conv, 12 virtual channels, depth-to-space store
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.a.up = 0; gh.b.up = 0;
         gh.H = H / 2; gh.W = W / 2;
-        gh.wsplit = L.d_wsplit_d2s; gh.bias = L.d_bias32_d2s;
+        // fp16-weight mode: the virtual-channel weights are sums of fp16-ROUNDED taps and keep their hi/lo split (rounding the
+        // sums again would not be "the conv with fp16 weights")
+        gh.wsplit = s->impl == AIPT_DN_IMPL_MFMA_F16W ? L.d_wsplit_d2s16 : L.d_wsplit_d2s; gh.bias = L.d_bias32_d2s;
         gh.cout = 4 * L.cout; gh.coutp = 32;
         gh.nchunks = L.nchunks16; gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
@@ -1231,7 +1240,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const dim3 grid((W + 15) / 16, (H + 15) / 16);
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
         hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
-    } else if (s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_small_min_pixels()) {
+    } else if (impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
@@ -1248,13 +1257,19 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,%d,%s>", gh.a.planar ? 8 : rows, gh.a.planar ? "true" : "false");
+        const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,%d,%s,%s>", gh.a.planar ? 8 : rows, gh.a.planar ? "true" : "false",
+                 w16 ? "true" : "false");
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
+        const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
         if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
-            hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
-        } else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, ctx->stream, gh);
+            if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
+        } else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
+        else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(grid_1d(grid.x, (H + 3) / 4, grid.z)), dim3(256), 0, ctx->stream, gh);
+        else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, ctx->stream, gh);
         else if (rows == 4) hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
         else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
         else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
@@ -1371,35 +1386,38 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             AIPT_HIP(ctx, hipMemcpy(L.d_bias_d2s, bv.data(), vnp * 4, hipMemcpyHostToDevice));
             // the same virtual-channel weights, split and tiled for conv3x3_f16x3 (one group of 32, K16 concat space)
             const int cbv = L.cin - L.ca, nch = pad16(L.ca) / KH + pad16(cbv) / KH;
-            std::vector<float> wf((size_t)vco * (nch * KH) * 9, 0.0f);                 // [v][kc][tap]
-            for (int par = 0; par < 4; par++) {
-                const int a = par >> 1, bb = par & 1;
-                for (int j = 0; j < L.cout; j++)
-                    for (int c = 0; c < L.cin; c++) {
-                        const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
-                        for (int ky = 0; ky < 3; ky++)
-                            for (int kx = 0; kx < 3; kx++) {
-                                const int dy = (a + ky + 1) / 2 - 1, dx = (bb + kx + 1) / 2 - 1;
-                                wf[((size_t)(par * L.cout + j) * (nch * KH) + kc) * 9 + (dy + 1) * 3 + (dx + 1)] +=
-                                    w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx];
-                            }
-                    }
+            for (int rounded = 0; rounded < 2; rounded++) {       // 1: taps rounded to fp16 first (AIPT_DN_IMPL_MFMA_F16W)
+                std::vector<float> wf((size_t)vco * (nch * KH) * 9, 0.0f);                 // [v][kc][tap]
+                for (int par = 0; par < 4; par++) {
+                    const int a = par >> 1, bb = par & 1;
+                    for (int j = 0; j < L.cout; j++)
+                        for (int c = 0; c < L.cin; c++) {
+                            const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
+                            for (int ky = 0; ky < 3; ky++)
+                                for (int kx = 0; kx < 3; kx++) {
+                                    const int dy = (a + ky + 1) / 2 - 1, dx = (bb + kx + 1) / 2 - 1;
+                                    wf[((size_t)(par * L.cout + j) * (nch * KH) + kc) * 9 + (dy + 1) * 3 + (dx + 1)] +=
+                                        (rounded ? (float)(_Float16)w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx] : w[((size_t)j * L.cin + c) * 9 + ky * 3 + kx]);
+                                }
+                        }
+                }
+                std::vector<_Float16> ws((size_t)nch * (WSLAB / 2), (_Float16)0.0f);
+                for (int v = 0; v < vco; v++)
+                    for (int kc = 0; kc < nch * KH; kc++)
+                        for (int t = 0; t < 9; t++) {
+                            const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t];
+                            const _Float16 h = (_Float16)x;
+                            const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v) * KH + (kc % KH);
+                            ws[o] = h;
+                            ws[o + 9 * 32 * KH] = (_Float16)((x - (float)h) * 2048.0f);
+                        }
+                unsigned char*& dst_w = rounded ? L.d_wsplit_d2s16 : L.d_wsplit_d2s;
+                AIPT_HIP(ctx, hipMalloc((void**)&dst_w, ws.size() * 2));
+                AIPT_HIP(ctx, hipMemcpy(dst_w, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
             }
-            std::vector<_Float16> ws((size_t)nch * (WSLAB / 2), (_Float16)0.0f);
-            for (int v = 0; v < vco; v++)
-                for (int kc = 0; kc < nch * KH; kc++)
-                    for (int t = 0; t < 9; t++) {
-                        const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t];
-                        const _Float16 h = (_Float16)x;
-                        const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v) * KH + (kc % KH);
-                        ws[o] = h;
-                        ws[o + 9 * 32 * KH] = (_Float16)((x - (float)h) * 2048.0f);
-                    }
             std::vector<float> b32v(32, 0.0f);
             for (int v = 0; v < vco; v++) b32v[v] = bv[v];
-            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit_d2s, ws.size() * 2));
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias32_d2s, 32 * 4));
-            AIPT_HIP(ctx, hipMemcpy(L.d_wsplit_d2s, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
             AIPT_HIP(ctx, hipMemcpy(L.d_bias32_d2s, b32v.data(), 32 * 4, hipMemcpyHostToDevice));
         }
         {   // split-fp16 weights, pre-tiled per (output-channel group, chunk) slab
@@ -1436,6 +1454,12 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         AIPT_HIP(ctx, hipMalloc((void**)&L.d_ab_running, L.cout * sizeof(float2)));
         AIPT_HIP(ctx, hipMemcpy(L.d_w, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(L.d_w_raw, w, (size_t)9 * L.cin * L.cout * 4, hipMemcpyHostToDevice));
+        {
+            std::vector<float> w16((size_t)9 * L.cin * L.cout);
+            for (size_t k = 0; k < w16.size(); k++) w16[k] = (float)(_Float16)w[k];
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_w_raw16, w16.size() * 4));
+            AIPT_HIP(ctx, hipMemcpy(L.d_w_raw16, w16.data(), w16.size() * 4, hipMemcpyHostToDevice));
+        }
         AIPT_HIP(ctx, hipMemcpy(L.d_bias, bp.data(), L.NP * 4, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(L.d_gamma, gamma, L.cout * 4, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(L.d_beta, beta, L.cout * 4, hipMemcpyHostToDevice));
@@ -1493,7 +1517,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
 
 int aipt_denoise_set_impl(aipt_ctx* ctx, int impl) {
     AIPT_CHECK_CTX(ctx);
-    if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU && impl != AIPT_DN_IMPL_MFMA_F16X3) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
+    if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU && impl != AIPT_DN_IMPL_MFMA_F16X3 && impl != AIPT_DN_IMPL_MFMA_F16W) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
     state(ctx)->impl = impl;
     return AIPT_OK;
 }
@@ -1531,7 +1555,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94).  The split-fp16 conv reads it as it is; the other
     // implementations get a C4 copy first.
     in = s->In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
-    const bool direct = s->impl == AIPT_DN_IMPL_MFMA_F16X3 && (long)H * W >= f16_min_pixels();
+    const bool direct = impl_is_f16(s->impl) && (long)H * W >= f16_min_pixels();
     if (direct) {
         in.p = const_cast<float*>(d_in10); in.planar = 1;
     } else {

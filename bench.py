@@ -41,8 +41,8 @@ def main():
                     help="add the procedural Sponza-like atrium mesh with NTRI triangles (BASELINE configs[2]: 262144)")
     ap.add_argument("--bn", choices=["batch", "running"], default="batch")
     ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
-    ap.add_argument("--impl", choices=["f32", "f16x3"], default="f16x3",
-                    help="conv arithmetic: f32-input MFMA everywhere, or split-fp16 MFMA on the full-resolution levels")
+    ap.add_argument("--impl", choices=["f32", "f16x3", "f16w"], default="f16x3",
+                    help="conv arithmetic: f32-input MFMA (exact fp32 chain), split-fp16 MFMA (default), or split-fp16 activations x fp16 weights")
     ap.add_argument("--prefetch", action="store_true",
                     help="trace frame k+1 on a second stream during denoise k (aipt_frame_prefetch; measured +2%%, off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,7 +101,7 @@ def main():
     ctx.pathtrace_init(geoms, mats, faces, box if faces else None)
     ctx.load_weights(weight_blob)
     ctx.frame_configure(W, H)
-    ctx.denoise_set_impl(api.DN_IMPL_MFMA_F16X3 if args.impl == "f16x3" else api.DN_IMPL_MFMA)
+    ctx.denoise_set_impl({"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl])
     out = torch.empty(3, H, W, device=dev)
     bn_batch = args.bn == "batch"
     carry = args.hidden == "carry"
@@ -195,7 +195,8 @@ def main():
         gbps = bytes_per_frame * ncalls / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
         split = dominant.startswith("conv3x3_f16x3")
         # MFMA ceiling of the kernel's arithmetic: f32-input MFMA 157.3 TFLOP/s; split-fp16 = fp16 dense peak / 3 MFMAs
-        mfma_peak = MI355X_FP16_MFMA_TFLOPS / 3.0 if split else MI355X_FP32_MFMA_TFLOPS
+        mfma_per_product = 2.0 if args.impl == "f16w" else 3.0
+        mfma_peak = MI355X_FP16_MFMA_TFLOPS / mfma_per_product if split else MI355X_FP32_MFMA_TFLOPS
         ai = flops_per_frame / bytes_per_frame
         hbm_bound = ai < mfma_peak * 1e12 / MI355X_HBM_BPS
         traffic = None
@@ -208,7 +209,7 @@ def main():
                 traffic = None
         mfma = {"achieved_tflops_algorithmic": round(tflops, 2), "peak_tflops": round(mfma_peak, 1),
                 "frac": round(tflops / mfma_peak, 4),
-                "note": ("fp16 dense MFMA peak 2500 / 3 MFMAs per fp32-class product" if split else "f32-input MFMA peak")}
+                "note": (f"fp16 dense MFMA peak 2500 / {int(mfma_per_product)} MFMAs per product" if split else "f32-input MFMA peak")}
         hbm = {"achieved_GBps_algorithmic": round(gbps, 1), "peak_GBps": MI355X_HBM_BPS / 1e9,
                "frac": round(gbps * 1e9 / MI355X_HBM_BPS, 4)}
         roof = {"bound": "hbm" if hbm_bound else "mfma",
@@ -269,7 +270,9 @@ def main():
             "metric": metric_name, "value": round(fps, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (split-fp16 MFMA operands, fp32 accumulate)" if args.impl == "f16x3" else "f32", "data": "synthetic",
+            "dtype": {"f16x3": "f32 (split-fp16 MFMA operands, fp32 accumulate)", "f32": "f32",
+                      "f16w": "fp16 conv weights, f32 activations (split-fp16 MFMA operands), fp32 accumulate"}[args.impl],
+            "data": "synthetic",
             "config": {"workload": (f"Cornell box (7 primitives, no mesh)" if not args.mesh else
                                     f"Cornell walls + procedural Sponza-like atrium mesh ({args.mesh} triangles, BVH)")
                                    + f" {W}x{H}, 1spp, depth {depth}, orbit pan, BN {args.bn}-stats, hidden {args.hidden}, "

@@ -155,8 +155,10 @@ int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n);
 
 #define AIPT_DN_IMPL_MFMA     0     /* f32-input MFMA implicit-GEMM conv everywhere: bit-for-bit an fp32 FMA chain */
 #define AIPT_DN_IMPL_VALU     1     /* plain per-thread direct conv (slow; on-GPU cross-check of the MFMA kernels) */
-#define AIPT_DN_IMPL_MFMA_F16X3 2   /* DEFAULT: split-fp16 MFMA (hi/lo operands, 3 MFMAs per product, fp32-class accuracy) on
-                                       the levels with >= 14k pixels, f32 MFMA on the deep levels */
+#define AIPT_DN_IMPL_MFMA_F16X3 2   /* DEFAULT: split-fp16 MFMA (hi/lo operands, 3 MFMAs per product, fp32-class accuracy) */
+#define AIPT_DN_IMPL_MFMA_F16W 3    /* fp16 conv weights (BASELINE configs[4]): the weights are rounded to fp16, activations
+                                       stay split hi/lo, fp32 accumulation (2 MFMAs per product, half the weight traffic);
+                                       results = the reference model run with its conv weights rounded to fp16 */
 
 /* blob: flat weight file, format in ai_path_tracer_denoiser_amd/arch.py (header + 28 x {W,b,gamma,beta,mean,var}). */
 int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);

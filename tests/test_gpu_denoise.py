@@ -155,3 +155,24 @@ def test_rejects_bad_sizes_and_missing_weights():
     with pytest.raises(api.AiptError):
         c.load_weights(b"garbage-not-a-blob")
     c.close()
+
+
+@pytest.mark.parametrize("bn_batch", [True, False])
+def test_fp16_weight_mode_is_the_model_with_rounded_weights(ctx, bn_batch):
+    """AIPT_DN_IMPL_MFMA_F16W (BASELINE configs[4]: fp16 conv weights on MFMA) must equal the oracle run on a blob whose
+    conv weights were rounded to fp16 -- same 1e-3 bar -- and must differ from the fp32-weight result (it is not a no-op)."""
+    import oracle
+    H, W = 96, 160
+    blob = synth.make_blob(21)
+    params = arch.unpack_blob(blob)
+    for p in params.values():
+        p["w"] = p["w"].astype(np.float16).astype(np.float32)
+    blob16 = arch.pack_blob(params)
+    frames = [synth.make_gbuffer(H, W, seed=5, frame=k) for k in range(2)]
+    orc = oracle.DenoiseOracle(blob16, H, W)
+    refs = [orc.forward(x, bn_batch, k > 0) for k, x in enumerate(frames)]
+    got16 = _run_gpu(ctx, blob, frames, H, W, bn_batch, True, impl=api.DN_IMPL_MFMA_F16W)
+    got32 = _run_gpu(ctx, blob, frames, H, W, bn_batch, True, impl=api.DN_IMPL_MFMA_F16X3)
+    for k in range(2):
+        assert np.abs(got16[k] - refs[k]).max() < TOL, (k, float(np.abs(got16[k] - refs[k]).max()))
+    assert np.abs(got16[1] - got32[1]).max() > 1e-6

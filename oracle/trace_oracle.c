@@ -219,27 +219,36 @@ float orc_sphere_test(const orc_geom* sp, const float* ro_, const float* rd_, fl
     return vlength(vsub(r.origin, ip));
 }
 
-/* glm::intersectRayTriangle (gtx/intersect.inl:37-74) + triangleIntersectionTest (intersections.h:159-172) */
+/* glm::intersectRayTriangle (gtx/intersect.inl:37-74).  baryPosition is written component by component, so an early
+ * return leaves the later components as the caller passed them (the reference passes an uninitialised vec3,
+ * intersections.h:163). */
+static int glm_intersect_ray_triangle(v3 orig, v3 dir, v3 v0, v3 v1, v3 v2, v3* bary) {
+    const v3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+    const v3 p = vcross(dir, e2);
+    const float a = vdot(e1, p);
+    if (a < FLT_EPSILON) return 0;
+    const float ff = 1.0f / a;
+    const v3 s = vsub(orig, v0);
+    bary->x = ff * vdot(s, p);
+    if (bary->x < 0.0f) return 0;
+    if (bary->x > 1.0f) return 0;
+    const v3 q = vcross(s, e1);
+    bary->y = ff * vdot(dir, q);
+    if (bary->y < 0.0f) return 0;
+    if (bary->y + bary->x > 1.0f) return 0;
+    bary->z = ff * vdot(e2, q);
+    return bary->z >= 0.0f;
+}
+
+/* triangleIntersectionTest (intersections.h:159-172) */
 float orc_triangle_test(const orc_face* f, const float* ro, const float* rd, float* P, float* N) {
     const v3 orig = V(ro[0], ro[1], ro[2]), dir = V(rd[0], rd[1], rd[2]);
     const v3 v0 = V(f->v[0][0], f->v[0][1], f->v[0][2]);
     const v3 v1 = V(f->v[1][0], f->v[1][1], f->v[1][2]);
     const v3 v2 = V(f->v[2][0], f->v[2][1], f->v[2][2]);
-    const v3 e1 = vsub(v1, v0), e2 = vsub(v2, v0);
-    const v3 p = vcross(dir, e2);
-    const float a = vdot(e1, p);
-    if (a < FLT_EPSILON) return -1;
-    const float ff = 1.0f / a;
-    const v3 s = vsub(orig, v0);
-    const float bx = ff * vdot(s, p);
-    if (bx < 0.0f) return -1;
-    if (bx > 1.0f) return -1;
-    const v3 q = vcross(s, e1);
-    const float by = ff * vdot(dir, q);
-    if (by < 0.0f) return -1;
-    if (by + bx > 1.0f) return -1;
-    const float bz = ff * vdot(e2, q);
-    if (!(bz >= 0.0f)) return -1;
+    v3 bary = V(0, 0, 0);
+    if (!glm_intersect_ray_triangle(orig, dir, v0, v1, v2, &bary)) return -1;
+    const float bx = bary.x, by = bary.y, bz = bary.z;
     const float bw = 1.0f - bx - by;
     /* F8: the hit point weights v0,v1,v2 with (x, y, 1-x-y) although GLM's (x,y) weight v1,v2 */
     const v3 ip = vadd(vadd(vscale(v0, bx), vscale(v1, by)), vscale(v2, bw));
@@ -665,20 +674,34 @@ static void mat_inverse_transpose(const float* m, float* out) {          /* gtc/
 #undef M
 }
 
+static void mat_translate(const float* m, v3 v, float* r) {               /* gtc/matrix_transform.inl:40-50 */
+    float t[16];
+    memcpy(t, m, 64);
+    for (int row = 0; row < 4; row++)
+        t[12 + row] = ((m[0 + row] * v.x + m[4 + row] * v.y) + m[8 + row] * v.z) + m[12 + row];
+    memcpy(r, t, 64);
+}
+static void mat_scale(const float* m, v3 v, float* r) {                   /* gtc/matrix_transform.inl:122-131 */
+    float t[16];
+    for (int row = 0; row < 4; row++) {
+        t[0 + row] = m[0 + row] * v.x;
+        t[4 + row] = m[4 + row] * v.y;
+        t[8 + row] = m[8 + row] * v.z;
+        t[12 + row] = m[12 + row];
+    }
+    memcpy(r, t, 64);
+}
+
 /* utilityCore::buildTransformationMatrix (utilities.cpp:45-52) + scene.cpp:92-95; fills the three matrices of g
  * from g->translation / rotation (degrees) / scale. */
 void orc_build_geom(orc_geom* g) {
     float I[16], T[16], R[16], R2[16], S[16], TR[16];
     mat_identity(I);
-    /* translate(I, v): Result[3] = m[0]*v0 + m[1]*v1 + m[2]*v2 + m[3] */
-    memcpy(T, I, 64);
-    for (int r = 0; r < 4; r++)
-        T[12 + r] = ((I[0 + r] * g->translation[0] + I[4 + r] * g->translation[1]) + I[8 + r] * g->translation[2]) + I[12 + r];
+    mat_translate(I, V(g->translation[0], g->translation[1], g->translation[2]), T);
     mat_rotate(I, g->rotation[0] * (float)PI_F / 180, V(1, 0, 0), R);
     mat_rotate(I, g->rotation[1] * (float)PI_F / 180, V(0, 1, 0), R2); mat_mul(R, R2, R);
     mat_rotate(I, g->rotation[2] * (float)PI_F / 180, V(0, 0, 1), R2); mat_mul(R, R2, R);
-    for (int c = 0; c < 3; c++) for (int r = 0; r < 4; r++) S[c * 4 + r] = I[c * 4 + r] * g->scale[c];
-    for (int r = 0; r < 4; r++) S[12 + r] = I[12 + r];
+    mat_scale(I, V(g->scale[0], g->scale[1], g->scale[2]), S);
     mat_mul(T, R, TR);
     mat_mul(TR, S, g->transform);
     mat_inverse(g->transform, g->inverseTransform);
@@ -729,3 +752,45 @@ void orc_camera_orbit(orc_camera* cam, float zoom, float phi, float theta) {
     cam->position[1] = cp.y + cam->lookAt[1];
     cam->position[2] = cp.z + cam->lookAt[2];
 }
+
+/* ---------------------------------------------------------------- known-answer hooks (tests/test_oracle_trace_kats.py)
+ * One record in, one record out, in the layouts of oracle/ref_glm_kats.cpp (which evaluates the reference's vendored
+ * GLM + utilities.cpp on the same inputs). */
+void orc_kat_tri(const float* i, float* o) {
+    v3 bary = V(0, 0, 0);
+    const int hit = glm_intersect_ray_triangle(V(i[0], i[1], i[2]), V(i[3], i[4], i[5]), V(i[6], i[7], i[8]),
+                                               V(i[9], i[10], i[11]), V(i[12], i[13], i[14]), &bary);
+    o[0] = hit ? 1.0f : 0.0f; o[1] = bary.x; o[2] = bary.y; o[3] = bary.z;
+}
+void orc_kat_vec(const float* i, float* o) {
+    const v3 a = V(i[0], i[1], i[2]), b = V(i[3], i[4], i[5]);
+    const v3 c = vcross(a, b), n = vnormalize(a), r = vreflect(a, b), t = glm_refract(a, b, i[6]);
+    o[0] = vdot(a, b);
+    o[1] = c.x; o[2] = c.y; o[3] = c.z;
+    o[4] = vlength(a);
+    o[5] = n.x; o[6] = n.y; o[7] = n.z;
+    o[8] = r.x; o[9] = r.y; o[10] = r.z;
+    o[11] = t.x; o[12] = t.y; o[13] = t.z;
+}
+void orc_kat_mulmv(const float* i, float* o) {
+    const float* m = i;
+    const v3 r = mulMV(m, V(i[16], i[17], i[18]), i[19]);
+    o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    o[3] = (m[3] * i[16] + m[7] * i[17]) + (m[11] * i[18] + m[15] * i[19]);
+}
+void orc_kat_matmul(const float* i, float* o) { mat_mul(i, i + 16, o); }
+void orc_kat_trs(const float* i, float* o) {
+    orc_geom g;
+    memset(&g, 0, sizeof(g));
+    memcpy(g.translation, i, 12); memcpy(g.rotation, i + 3, 12); memcpy(g.scale, i + 6, 12);
+    orc_build_geom(&g);
+    memcpy(o, g.transform, 64); memcpy(o + 16, g.inverseTransform, 64); memcpy(o + 32, g.invTranspose, 64);
+}
+void orc_kat_xform(const float* i, float* o) {
+    const v3 v = V(i[17], i[18], i[19]);
+    mat_translate(i, v, o);
+    mat_rotate(i, i[16], v, o + 16);
+    mat_scale(i, v, o + 32);
+}
+void orc_kat_inverse(const float* i, float* o) { mat_inverse(i, o); mat_inverse_transpose(i, o + 16); }
+void orc_kat_minmax(const float* i, float* o) { o[0] = glm_min(i[0], i[1]); o[1] = glm_max(i[0], i[1]); }

@@ -39,6 +39,7 @@ def gpu_trace(ctx, sc, depth, rows=None, stride=None, flags=api.TRACE_DEFAULT | 
     stride = stride or W
     ctx.pathtrace_init(geoms, mats, faces, box, W, H)
     gbuf = torch.zeros(10, rows, stride, device="cuda")
+    torch.cuda.synchronize()          # the zero fill runs on torch's stream, the trace on the context's non-blocking stream
     ctx.pathtrace(cam, 1, depth, gbuf, flags)
     ctx.sync()
     return gbuf.cpu().numpy(), ctx.live_counts(depth), ctx.first_hit_materials(W * H)

@@ -74,3 +74,18 @@ def test_mesh_scene_and_errors(tmp_path):
     bad.write_text("MATERIAL 3\nRGB 1 1 1\n")
     with pytest.raises(api.AiptError):
         api.Scene(str(bad))
+
+
+def test_geom_build_matches_the_reference_glm_table(golden_dir):
+    """aipt_geom_build (csrc/scene.cpp) against tests/golden/trace_glm_kats.npz `trs`: the matrices the reference's own
+    utilityCore::buildTransformationMatrix + glm::inverse + glm::inverseTranspose produce (oracle/ref_glm_kats.cpp)."""
+    z = np.load(os.path.join(golden_dir, "trace_glm_kats.npz"))
+    x, want = z["trs_in"], z["trs_out"]
+    L = api.lib()
+    for k in range(len(x)):
+        g = api.Geom()
+        g.translation[:] = x[k, 0:3].tolist(); g.rotation[:] = x[k, 3:6].tolist(); g.scale[:] = x[k, 6:9].tolist()
+        L.aipt_geom_build(C.byref(g))
+        got = np.concatenate([np.frombuffer(bytes(g.transform), np.uint32), np.frombuffer(bytes(g.inverseTransform), np.uint32),
+                              np.frombuffer(bytes(g.invTranspose), np.uint32)])
+        assert np.array_equal(got, want[k]), f"row {k}"

@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libaiptd.so")
 
 # flags (include/aiptd.h)
 TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0, TRACE_BRUTE_FORCE, TRACE_NO_BROAD_PHASE = 1, 2, 4, 8, 16
+TRACE_SORT_MATERIAL, TRACE_CACHE_FIRST_BOUNCE, TRACE_MOTION_BLUR = 32, 64, 128
 TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
 DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
 DN_IMPL_MFMA, DN_IMPL_VALU, DN_IMPL_MFMA_F16X3, DN_IMPL_MFMA_F16W = 0, 1, 2, 3

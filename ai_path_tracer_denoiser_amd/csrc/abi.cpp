@@ -182,6 +182,7 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     }
     ctx->d_gbuf = ctx->d_gbufs[0];
     ctx->fw = width; ctx->fh = height; ctx->fwp = wp; ctx->fhp = hp;
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the zero fills are done before any stream (side included) traces
     return AIPT_OK;
 }
 
@@ -242,6 +243,9 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     if (cam->resolution[0] != ctx->fw || cam->resolution[1] != ctx->fh)
         return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: camera is %dx%d, configured %dx%d", cam->resolution[0],
                     cam->resolution[1], ctx->fw, ctx->fh);
+    // planes 3-9 are written at iter == 1 only and live in the G-buffer the iteration-1 trace wrote (pathtrace.cu:295,379): a
+    // later iteration traced into the OTHER buffer would be denoised with stale planes, so only iteration 1 can be prefetched
+    if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->side) AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     const int back = ctx->front ^ 1;

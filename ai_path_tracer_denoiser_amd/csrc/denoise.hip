@@ -1143,6 +1143,13 @@ static DenoiseState* state(aipt_ctx* ctx) {
     return ctx->dn;
 }
 
+// The name rocprofv3 reports for a conv3x3_f16x3<1, rows, planar, w16> instantiation, without blanks: bench.py and
+// tools/pmc_summarize.py match kernel rows of profiles/ on it, so every launch site takes it from here.
+static void f16x3_name(char* dst, size_t n, int rows, bool planar, bool w16) {
+    snprintf(dst, n, "conv3x3_f16x3<1,%d,%s,%s>", rows, planar ? "true" : "false", w16 ? "true" : "false");
+}
+#define F16X3_NAME_8ROW "conv3x3_f16x3<1,8,false,false>"
+
 template <int RW, int MBX, int NBB>
 static void launch_mfma(ConvArgs a, dim3 grid, hipStream_t st) {
     a.tiles_x = grid.x; a.tiles_y = grid.y; a.groups = grid.z;
@@ -1217,7 +1224,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = L.cout;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,8,false>");
+        snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
         hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, ctx->stream, gh);
     } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
@@ -1258,8 +1265,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = 0;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3<1,%d,%s,%s>", gh.a.planar ? 8 : rows, gh.a.planar ? "true" : "false",
-                 w16 ? "true" : "false");
+        f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
@@ -1325,6 +1331,9 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
     if (off + 4 * nfl != bytes) return fail(ctx, AIPT_E_FORMAT, "weight blob: %zu bytes, expected %zu", bytes, off + 4 * nfl);
     DenoiseState* s = state(ctx);
     free_weights(s);
+    // the carried hidden states reference the old layers' gamma/beta/statistics: a reload resets the recurrent state
+    s->hidden_valid = false;
+    for (Tensor& t : s->Hid) t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     std::vector<float> f(nfl);
     memcpy(f.data(), p + off, 4 * nfl);
     const float* q = f.data();

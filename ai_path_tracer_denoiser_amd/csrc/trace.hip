@@ -56,6 +56,13 @@ struct TraceState {
     int* d_nlive = nullptr;       // [MAX_DEPTH+1]
     int* d_mat0 = nullptr;        // [P]
     float* d_image = nullptr;     // [3][P] radiance accumulated over iterations 1..n (dev_image, pathtrace.cu:101), h-flipped
+    float* d_cache = nullptr;     // [8][P] bounce-0 hit records of iteration 1 (AIPT_TRACE_CACHE_FIRST_BOUNCE): t, material, P, raw N
+    int* d_live3 = nullptr;       // third live list (AIPT_TRACE_SORT_MATERIAL: compact -> sort -> next bounce)
+    int* d_sortkey = nullptr;     // [P] material id of the hit found in array slot t at the current bounce (0 = miss)
+    int* d_hist = nullptr;        // [nkeys][nblk] counting-sort histogram / bases
+    int hist_keys = 0;
+    bool cache_valid = false;
+    std::vector<aipt_geom> h_geoms;   // host copy for AIPT_TRACE_MOTION_BLUR (moveGeom, pathtrace.cu:318-331)
     int last_depth = 0;
     bool mat0_valid = false;
 };
@@ -78,8 +85,12 @@ struct TraceParams {
     int* n_live;
     int* mat0;
     float* image;
-    const int* live_in;          // pixel indices of the live paths entering this bounce, in pixel order (nullptr: all pixels)
+    const int* live_in;          // pixel indices of the live paths entering this bounce, in array order (nullptr: all pixels)
     int* live_out;
+    float* cache; int cache_mode;   // 0: none, 1: save the bounce-0 hit records, 2: reuse them instead of intersecting
+    int* sortkey;                   // AIPT_TRACE_SORT_MATERIAL: material id of the hit in array slot t (0 = miss)
+    int* hist; int nkeys, nblk;
+    const int* sort_in; int* sort_out;
 };
 
 // ---------------------------------------------------------------------------------------------- vector helpers
@@ -408,6 +419,13 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
         float t_min = FLT_MAX;
         int materialid = -1;
         v3 hitP = V(0, 0, 0), normal = V(0, 0, 0);
+        const bool from_cache = FIRST && p.cache_mode == 2;        // CACHE_BOUNCE, iter > 1 (pathtrace.cu:473-476)
+        if (from_cache) {
+            const float* c = p.cache + i;
+            t_min = c[0]; materialid = __float_as_int(c[(size_t)P]);
+            hitP = V(c[(size_t)2 * P], c[(size_t)3 * P], c[(size_t)4 * P]);
+            normal = V(c[(size_t)5 * P], c[(size_t)6 * P], c[(size_t)7 * P]);
+        } else
         if (broad) {
             // broad phase over all primitives (wave-uniform loop, scalar loads), then the exact tests on this lane's
             // candidates only, in index order (so "the first of equal distances wins" as in the reference's loop): a
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                 if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
             }
         }
-        if (MESH && p.nfaces && rayAABB(o, d, p.box)) {                                  // RAY_CULLING true (:23, :258)
+        if (MESH && !from_cache && p.nfaces && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -491,6 +509,13 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             }
         }
         const bool hit = materialid != -1;
+        if (FIRST && p.cache_mode == 1) {                          // CACHE_BOUNCE, iter == 1 (:466-472)
+            float* c = p.cache + i;
+            c[0] = t_min; c[(size_t)P] = __int_as_float(materialid);
+            c[(size_t)2 * P] = hitP.x; c[(size_t)3 * P] = hitP.y; c[(size_t)4 * P] = hitP.z;
+            c[(size_t)5 * P] = normal.x; c[(size_t)6 * P] = normal.y; c[(size_t)7 * P] = normal.z;
+        }
+        if (p.sortkey) p.sortkey[FIRST ? i : t] = hit ? materialid : 0;   // the hit record's materialId (memset 0, :478)
         const v3 surfN = vnormalize(normal);
         const int x = i % p.W, y = i / p.W;
         const size_t gd = (size_t)y * p.stride + (size_t)(p.W - x - 1);         // h-flipped destination (:297-299)
@@ -590,11 +615,69 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     if (alive) p.live_out[base + woff + __popcll(mask & ((1ull << lane) - 1ull))] = i;
 }
 
+// ---- AIPT_TRACE_SORT_MATERIAL: stable counting sort of the compacted live list by material id ------------------------------
+// The reference sorts the surviving PathSegments with thrust::sort_by_key (pathtrace.cu:508-510; a stable merge sort).  Its
+// keys are the hit records the PRE-partition array slots hold, so slot j of the compacted list is keyed by sortkey[j], the
+// material id the bounce kernel found for array slot j (0 for a miss).  Three small launches over the 4-byte list:
+// per-workgroup histograms, one exclusive scan in (key, workgroup) order, stable scatter by ballot rank.
+__global__ __launch_bounds__(256) void trace_sort_hist(const TraceParams p) {
+    __shared__ int s_cnt[256];
+    const int tid = threadIdx.x;
+    const int n = p.n_live[p.bounce + 1];
+    s_cnt[tid] = 0;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + tid;
+    if (t < n) atomicAdd(&s_cnt[p.sortkey[t]], 1);
+    __syncthreads();
+    if (tid < p.nkeys) p.hist[tid * p.nblk + blockIdx.x] = s_cnt[tid];
+}
+__global__ __launch_bounds__(1024) void trace_sort_scan(const TraceParams p) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int total = p.nkeys * p.nblk;
+    const int per = (total + 1023) / 1024;
+    const int lo = tid * per, hi = min(total, lo + per);
+    int sum = 0;
+    for (int k = lo; k < hi; k++) sum += p.hist[k];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                       // inclusive Hillis-Steele scan of the 1024 partial sums
+        const int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int k = lo; k < hi; k++) { const int c = p.hist[k]; p.hist[k] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void trace_sort_scatter(const TraceParams p) {
+    __shared__ int s_wave[4][256];                              // per-wave count of every key
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n_live[p.bounce + 1];
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int t = blockIdx.x * 256 + tid;
+    const bool in = t < n;
+    const int key = in ? p.sortkey[t] : -1;
+    int rank = 0;
+    for (int k = 0; k < p.nkeys; k++) {                        // wave-uniform loop; keys are few (materials)
+        const unsigned long long m = __ballot(key == k);
+        if (key == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave][k] = __popcll(m);
+    }
+    __syncthreads();
+    if (in) {
+        int off = p.hist[key * p.nblk + blockIdx.x];
+        for (int w = 0; w < wave; w++) off += s_wave[w][key];
+        p.sort_out[off + rank] = p.sort_in[t];
+    }
+}
+
 void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
     hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
     hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image); hipFree(s->d_live[0]); hipFree(s->d_live[1]);
+    hipFree(s->d_cache); hipFree(s->d_live3); hipFree(s->d_sortkey); hipFree(s->d_hist);
     delete s;
     ctx->trace = nullptr;
 }
@@ -602,6 +685,34 @@ void trace_destroy(aipt_ctx* ctx) {
 static TraceState* tstate(aipt_ctx* ctx) {
     if (!ctx->trace) ctx->trace = new TraceState();
     return ctx->trace;
+}
+
+// device form of one primitive: the three matrices + the padded world box of the broad phase
+static DevGeom make_dev_geom(const aipt_geom& g) {
+    DevGeom d;
+    d.type = g.type; d.materialid = g.materialid;
+    memcpy(d.inv, g.inverseTransform, 64);
+    memcpy(d.xf, g.transform, 64);
+    memcpy(d.invT, g.invTranspose, 64);
+    // padded world box of the unit cube [-0.5, 0.5]^3 under the primitive's transform (encloses the unit sphere too)
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    const float* m = g.transform;                             // column-major
+    for (int c = 0; c < 8; c++) {
+        const double x = (c & 1) ? 0.5 : -0.5, y = (c & 2) ? 0.5 : -0.5, z = (c & 4) ? 0.5 : -0.5;
+        for (int r = 0; r < 3; r++) {
+            const double v = (double)m[0 * 4 + r] * x + (double)m[1 * 4 + r] * y + (double)m[2 * 4 + r] * z + (double)m[3 * 4 + r];
+            if (v < lo[r]) lo[r] = v;
+            if (v > hi[r]) hi[r] = v;
+        }
+    }
+    double scale = 1.0;
+    for (int r = 0; r < 3; r++) { scale = fmax(scale, hi[r] - lo[r]); scale = fmax(scale, fmax(fabs(lo[r]), fabs(hi[r]))); }
+    for (int r = 0; r < 3; r++) {
+        d.lo[r] = (float)(lo[r] - 1e-3 * scale);
+        d.hi[r] = (float)(hi[r] + 1e-3 * scale);
+        if (!(d.lo[r] <= d.hi[r])) { d.lo[r] = -3.0e38f; d.hi[r] = 3.0e38f; }   // NaN/inf transform: never cull
+    }
+    return d;
 }
 
 }  // namespace aipt
@@ -629,30 +740,8 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
     s->d_nodes = nullptr; s->d_lfaces = nullptr; s->d_lidx = nullptr; s->nnodes = 0;
     std::vector<DevGeom> dg(ngeoms);
-    for (int i = 0; i < ngeoms; i++) {
-        dg[i].type = geoms[i].type; dg[i].materialid = geoms[i].materialid;
-        memcpy(dg[i].inv, geoms[i].inverseTransform, 64);
-        memcpy(dg[i].xf, geoms[i].transform, 64);
-        memcpy(dg[i].invT, geoms[i].invTranspose, 64);
-        // padded world box of the unit cube [-0.5, 0.5]^3 under the primitive's transform (encloses the unit sphere too)
-        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-        const float* m = geoms[i].transform;                  // column-major
-        for (int c = 0; c < 8; c++) {
-            const double x = (c & 1) ? 0.5 : -0.5, y = (c & 2) ? 0.5 : -0.5, z = (c & 4) ? 0.5 : -0.5;
-            for (int r = 0; r < 3; r++) {
-                const double v = (double)m[0 * 4 + r] * x + (double)m[1 * 4 + r] * y + (double)m[2 * 4 + r] * z + (double)m[3 * 4 + r];
-                if (v < lo[r]) lo[r] = v;
-                if (v > hi[r]) hi[r] = v;
-            }
-        }
-        double scale = 1.0;
-        for (int r = 0; r < 3; r++) { scale = fmax(scale, hi[r] - lo[r]); scale = fmax(scale, fmax(fabs(lo[r]), fabs(hi[r]))); }
-        for (int r = 0; r < 3; r++) {
-            dg[i].lo[r] = (float)(lo[r] - 1e-3 * scale);
-            dg[i].hi[r] = (float)(hi[r] + 1e-3 * scale);
-            if (!(dg[i].lo[r] <= dg[i].hi[r])) { dg[i].lo[r] = -3.0e38f; dg[i].hi[r] = 3.0e38f; }   // NaN/inf transform: never cull
-        }
-    }
+    for (int i = 0; i < ngeoms; i++) dg[i] = make_dev_geom(geoms[i]);
+    s->h_geoms.assign(geoms, geoms + ngeoms);
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_geoms, sizeof(DevGeom) * (ngeoms ? ngeoms : 1)));
     if (ngeoms) AIPT_HIP(ctx, hipMemcpy(s->d_geoms, dg.data(), sizeof(DevGeom) * ngeoms, hipMemcpyHostToDevice));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_mats, sizeof(aipt_material) * nmaterials));
@@ -677,7 +766,7 @@ int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const a
         s->nnodes = (int)nodes.size();
     }
     s->ngeoms = ngeoms; s->nmats = nmaterials; s->nfaces = nfaces;
-    s->have_scene = true;
+    s->have_scene = true; s->cache_valid = false;
     return AIPT_OK;
 }
 
@@ -701,6 +790,8 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
     hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
     hipFree(s->d_live[0]); hipFree(s->d_live[1]);
+    hipFree(s->d_cache); hipFree(s->d_live3); hipFree(s->d_sortkey); hipFree(s->d_hist);
+    s->d_cache = nullptr; s->d_live3 = nullptr; s->d_sortkey = nullptr; s->d_hist = nullptr; s->hist_keys = 0;
     s->d_live[0] = s->d_live[1] = nullptr;
     s->d_state = nullptr; s->d_cnt[0] = s->d_cnt[1] = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
     const int P = width * height, nblk = (P + 255) / 256;
@@ -713,7 +804,7 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[0], sizeof(int) * (size_t)P));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[1], sizeof(int) * (size_t)P));
     s->W = width; s->H = height; s->P = P; s->nblk = nblk;
-    s->mat0_valid = false;
+    s->mat0_valid = false; s->cache_valid = false;
     return AIPT_OK;
 }
 
@@ -737,6 +828,42 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     if (depth < 1 || depth > MAX_DEPTH) return fail(ctx, AIPT_E_INVALID, "aipt_trace: depth %d not in 1..%d", depth, MAX_DEPTH);
     if (iter < 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace: iter %d (iterations count from 1, main.cpp:149)", iter);
     if (gbuf_rows < s->H || gbuf_stride < s->W) return fail(ctx, AIPT_E_INVALID, "aipt_trace: G-buffer %dx%d too small", gbuf_rows, gbuf_stride);
+    const bool sortmat = (flags & AIPT_TRACE_SORT_MATERIAL) != 0, cache = (flags & AIPT_TRACE_CACHE_FIRST_BOUNCE) != 0;
+    const bool blur = (flags & AIPT_TRACE_MOTION_BLUR) != 0;
+    if (sortmat && !(flags & AIPT_TRACE_COMPACT))
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_SORT_MATERIAL needs AIPT_TRACE_COMPACT");
+    if (sortmat && s->nmats > 256) return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_SORT_MATERIAL supports up to 256 materials (%d)", s->nmats);
+    if (cache && ((flags & AIPT_TRACE_AA) || blur))             // the reference's asserts, pathtrace.cu:435-436
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE is only legal without AIPT_TRACE_AA and AIPT_TRACE_MOTION_BLUR");
+    if (cache && !s->d_cache) AIPT_HIP(ctx, hipMalloc((void**)&s->d_cache, sizeof(float) * 8 * (size_t)s->P));
+    if (cache && iter > 1 && !s->cache_valid)
+        return fail(ctx, AIPT_E_STATE, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE at iter %d without a cached iter 1", iter);
+    if (sortmat) {
+        if (!s->d_live3) AIPT_HIP(ctx, hipMalloc((void**)&s->d_live3, sizeof(int) * (size_t)s->P));
+        if (!s->d_sortkey) AIPT_HIP(ctx, hipMalloc((void**)&s->d_sortkey, sizeof(int) * (size_t)s->P));
+        if (s->hist_keys < s->nmats) {
+            AIPT_HIP(ctx, hipStreamSynchronize(st));
+            hipFree(s->d_hist); s->d_hist = nullptr;
+            AIPT_HIP(ctx, hipMalloc((void**)&s->d_hist, sizeof(int) * (size_t)s->nmats * s->nblk));
+            s->hist_keys = s->nmats;
+        }
+    }
+    if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
+    if (blur && !(iter % 4) && iter < 3000) {                   // moveGeom, pathtrace.cu:442-446 (dt = 0.10)
+        bool moved = false;
+        for (aipt_geom& g : s->h_geoms) {
+            if (g.vel[0] == 0.0f && g.vel[1] == 0.0f && g.vel[2] == 0.0f) continue;
+            for (int a = 0; a < 3; a++) g.translation[a] += g.vel[a] * 0.10f;
+            aipt_geom_build(&g);
+            moved = true;
+        }
+        if (moved) {
+            std::vector<DevGeom> dg(s->ngeoms);
+            for (int i = 0; i < s->ngeoms; i++) dg[i] = make_dev_geom(s->h_geoms[i]);
+            AIPT_HIP(ctx, hipStreamSynchronize(st));            // earlier traces still read the old primitives
+            AIPT_HIP(ctx, hipMemcpy(s->d_geoms, dg.data(), sizeof(DevGeom) * s->ngeoms, hipMemcpyHostToDevice));
+        }
+    }
     TraceParams p;
     p.cam = *cam; p.iter = iter; p.trace_depth = depth; p.flags = flags;
     p.W = s->W; p.H = s->H; p.P = s->P;
@@ -748,22 +875,40 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     p.n_live = s->d_nlive;
     p.mat0 = (flags & AIPT_TRACE_RECORD_MAT0) ? s->d_mat0 : nullptr;
     p.image = s->d_image;
-    if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
+    p.cache = s->d_cache; p.cache_mode = cache ? (iter == 1 ? 1 : 2) : 0;
+    p.sortkey = sortmat ? s->d_sortkey : nullptr;
+    p.hist = s->d_hist; p.nkeys = s->nmats; p.nblk = s->nblk;
+    p.sort_in = nullptr; p.sort_out = nullptr;
     AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), st));
+    int* lists[3] = {s->d_live[0], s->d_live[1], s->d_live3};
+    int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
         p.cnt_in = nullptr;
         p.cnt_out = s->d_cnt[0];
-        p.live_in = b == 0 ? nullptr : s->d_live[b & 1];
-        p.live_out = s->d_live[(b + 1) & 1];
+        p.live_in = cur < 0 ? nullptr : lists[cur];
+        const int nxt = cur < 0 ? 0 : (cur + 1) % (sortmat ? 3 : 2);
+        p.live_out = lists[nxt];
         const bool mesh = s->nfaces > 0;
         const size_t stack_bytes = mesh ? (size_t)(s->bvh_depth + 1) * 256 * sizeof(int) : 0;
         if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(s->nblk), dim3(256), 0, st, p);
         else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
         else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(s->nblk), dim3(256), 0, st, p);
-        if (b + 1 < depth) hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
+        if (b + 1 < depth) {
+            hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
+            cur = nxt;
+            if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)
+                const int srt = (cur + 1) % 3;
+                p.sort_in = lists[cur]; p.sort_out = lists[srt];
+                hipLaunchKernelGGL(trace_sort_hist, dim3(s->nblk), dim3(256), 0, st, p);
+                hipLaunchKernelGGL(trace_sort_scan, dim3(1), dim3(1024), 0, st, p);
+                hipLaunchKernelGGL(trace_sort_scatter, dim3(s->nblk), dim3(256), 0, st, p);
+                cur = srt;
+            }
+        }
     }
+    if (cache && iter == 1) s->cache_valid = true;
     AIPT_HIP(ctx, hipGetLastError());
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
     ctx->last_trace_stream = st;

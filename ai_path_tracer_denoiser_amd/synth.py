@@ -136,11 +136,15 @@ def _grid_surface(fn, nu, nv, material, flip=False):
     return faces
 
 
-def make_atrium_mesh(n_triangles=262144, seed=565, material=1):
+def make_atrium_mesh(n_triangles=262144, seed=565, material=1, floor_material=None, column_material=None):
     """"Sponza-like" atrium inside the 10 x 10 x 10 Cornell volume: two rows of columns, arches between neighbouring
     columns, a gently rippled floor slab and a few spheres.  Returns (faces[FACE_DTYPE], lb[3], ub[3]) with exactly
-    n_triangles triangles (the floor grid absorbs the remainder).  Deterministic for a given (n_triangles, seed)."""
+    n_triangles triangles (the floor grid absorbs the remainder).  Deterministic for a given (n_triangles, seed).
+    floor_material / column_material (default: material) give the floor slab and the columns their own material ids --
+    BASELINE configs[3] ("reflective Sponza") sets both to the reflective material."""
     assert n_triangles >= 2048
+    floor_material = material if floor_material is None else floor_material
+    column_material = material if column_material is None else column_material
     rng_u = uniform01(64, seed, 9001).astype(np.float64)
     parts = []
     ncol = 6
@@ -166,7 +170,7 @@ def make_atrium_mesh(n_triangles=262144, seed=565, material=1):
                 p = np.stack([x + r * bulge * np.cos(ang), 0.02 + 6.0 * v, z + r * bulge * np.sin(ang)], -1)
                 n = np.stack([np.cos(ang), -0.08 * np.pi * np.cos(np.pi * v) * r / 6.0, np.sin(ang)], -1)
                 return p, n
-            parts.append(_grid_surface(col, nu, nv, material))
+            parts.append(_grid_surface(col, nu, nv, column_material))
         for ci in range(ncol - 1):
             x0, x1 = xs[ci], xs[ci + 1]
             nu, nv = dims(arch_tris)
@@ -208,7 +212,7 @@ def make_atrium_mesh(n_triangles=262144, seed=565, material=1):
         dydx = 0.015 * 3.0 * np.cos(3.0 * x) * np.cos(2.5 * z)
         dydz = -0.015 * 2.5 * np.sin(3.0 * x) * np.sin(2.5 * z)
         return np.stack([x, y, z], -1), np.stack([-dydx, np.ones_like(x), -dydz], -1)
-    parts.append(_grid_surface(floor, nu, nv, material))
+    parts.append(_grid_surface(floor, nu, nv, floor_material))
     faces = np.concatenate(parts)
     assert len(faces) == n_triangles
     verts = faces["v"].reshape(-1, 3)
@@ -216,6 +220,138 @@ def make_atrium_mesh(n_triangles=262144, seed=565, material=1):
     # Scene::loadObj starts the upper bound at FLT_MIN, the smallest positive float (scene.cpp:216-218)
     ub = np.maximum(verts.max(axis=0), np.float32(np.finfo(np.float32).tiny))
     return faces, lb.astype(np.float32), ub.astype(np.float32)
+
+
+def _mesh_bounds(faces):
+    verts = faces["v"].reshape(-1, 3)
+    lb = verts.min(axis=0)
+    # Scene::loadObj starts the upper bound at FLT_MIN, the smallest positive float (scene.cpp:216-218)
+    ub = np.maximum(verts.max(axis=0), np.float32(np.finfo(np.float32).tiny))
+    return lb.astype(np.float32), ub.astype(np.float32)
+
+
+# Material records in the reference's 44-byte layout (sceneStructs.h:46-56); bytes(...) of one element converts to the
+# ctypes Material of api.py / oracle via from_buffer_copy.
+MATERIAL_DTYPE = np.dtype([("color", np.float32, 3), ("specex", np.float32), ("speccolor", np.float32, 3),
+                           ("refl", np.float32), ("refr", np.float32), ("ior", np.float32), ("emit", np.float32)])
+assert MATERIAL_DTYPE.itemsize == 44
+
+
+def material(rgb, spec=(0, 0, 0), refl=0.0, refr=0.0, ior=0.0, emit=0.0) -> bytes:
+    m = np.zeros(1, MATERIAL_DTYPE)
+    m["color"] = rgb; m["speccolor"] = spec; m["refl"] = refl; m["refr"] = refr; m["ior"] = ior; m["emit"] = emit
+    return m.tobytes()
+
+
+STONE = material((.75, .7, .6))                                          # all-diffuse stone
+# `REFL 1 SPECRGB .9 .9 .9` with REFR 0 REFRIOR 0 as the reference's reflective material
+# (scenes/Scenes/cornell_all_materials.txt:42-49): scatterRay then runs refract() with eta = 1/0 = inf or 0
+MIRROR = material((.98, .98, .98), spec=(.9, .9, .9), refl=1.0)
+GLASS = material((.9, .95, 1.0), spec=(.98, .98, .98), refr=1.0, ior=1.33)   # `REFR 1 REFRIOR 1.33`
+FABRIC = material((.55, .25, .2))
+WOOD = material((.6, .45, .3))
+WHITE = material((.9, .9, .85))
+
+
+def make_living_room_mesh(n_triangles=524288, seed=565, first_material=0):
+    """"Living-room-like" interior inside the 10 x 10 x 10 Cornell volume (BASELINE configs[4]): mixed diffuse,
+    reflective and refractive face materials.  Returns (faces, lb, ub, materials) where materials is the list of 44-byte
+    material records the mesh uses; face material ids start at first_material (append the list to the scene's materials).
+    Parts: wooden floor, rippled rug, three sofa cushions and a back rest (fabric), a glass table top on four chrome legs,
+    two glass vases (surfaces of revolution), a wall mirror, a chrome torus ornament, a white lamp shade.
+    Deterministic for a given (n_triangles, seed); the rug grid absorbs the remainder so the count is exact."""
+    assert n_triangles >= 4096
+    mats = [WOOD, FABRIC, GLASS, MIRROR, WHITE, STONE]
+    WOOD_I, FABRIC_I, GLASS_I, MIRROR_I, WHITE_I, STONE_I = [first_material + k for k in range(6)]
+    r = uniform01(64, seed, 9101).astype(np.float64)
+    parts = []
+
+    def dims(target, aspect=2.0):
+        nv = max(2, int(np.sqrt(target / (2.0 * aspect))))
+        nu = max(3, int(target // (2 * nv)))
+        return nu, nv
+
+    def ellipsoid(c, a):
+        c, a = np.asarray(c, float), np.asarray(a, float)
+
+        def f(u, v):
+            ang, pol = 2 * np.pi * u, np.pi * (0.01 + 0.98 * v)
+            d = np.stack([np.sin(pol) * np.cos(ang), np.cos(pol), np.sin(pol) * np.sin(ang)], -1)
+            return c + a * d, d / a
+        return f
+
+    def revolve(c, profile, dprofile, height):
+        c = np.asarray(c, float)
+
+        def f(u, v):
+            ang = 2 * np.pi * u
+            rad, drad = profile(v), dprofile(v)
+            p = np.stack([c[0] + rad * np.cos(ang), c[1] + height * v, c[2] + rad * np.sin(ang)], -1)
+            n = np.stack([np.cos(ang), -drad / height, np.sin(ang)], -1)
+            return p, n
+        return f
+
+    def plane_xy(x0, x1, y0, y1, z):
+        def f(u, v):
+            p = np.stack([x0 + (x1 - x0) * u, y0 + (y1 - y0) * v, np.full_like(u, z)], -1)
+            return p, np.broadcast_to(np.array([0.0, 0.0, 1.0]), p.shape).copy()
+        return f
+
+    def torus(c, R, rt):
+        c = np.asarray(c, float)
+
+        def f(u, v):
+            th, ph = 2 * np.pi * u, 2 * np.pi * v
+            n = np.stack([np.cos(ph) * np.cos(th), np.sin(ph), np.cos(ph) * np.sin(th)], -1)
+            p = c + np.stack([(R + rt * np.cos(ph)) * np.cos(th), rt * np.sin(ph), (R + rt * np.cos(ph)) * np.sin(th)], -1)
+            return p, n
+        return f
+
+    B = n_triangles
+
+    def add(fn, share, mat, aspect=2.0):
+        nu, nv = dims(int(B * share), aspect)
+        parts.append(_grid_surface(fn, nu, nv, mat))
+
+    for k in range(3):                                                            # sofa cushions
+        add(ellipsoid([-2.2 + 2.2 * k, 1.0 + 0.05 * r[k], -2.6], [1.0, 0.45, 0.9]), 0.07, FABRIC_I)
+    add(ellipsoid([0.0, 2.0, -3.5], [3.3, 1.0, 0.35]), 0.07, FABRIC_I)            # back rest
+    add(ellipsoid([0.3, 1.55, 0.6], [1.7, 0.07, 1.0]), 0.08, GLASS_I)             # glass table top
+    for k, (lx, lz) in enumerate([(-0.9, 0.0), (1.5, 0.0), (-0.9, 1.2), (1.5, 1.2)]):   # chrome legs
+        add(revolve([lx, 0.03, lz], lambda v: 0.06 + 0.0 * v, lambda v: 0.0 * v, 1.45), 0.015, MIRROR_I)
+    for k, (vx, vz) in enumerate([(3.2, -1.0), (-3.4, 1.8)]):                     # glass vases
+        h = 1.6 + 0.4 * r[10 + k]
+        add(revolve([vx, 0.03, vz], lambda v: 0.25 + 0.2 * np.sin(np.pi * v) ** 2 + 0.05 * np.cos(3 * np.pi * v),
+                    lambda v: 0.2 * np.pi * np.sin(2 * np.pi * v) - 0.15 * np.pi * np.sin(3 * np.pi * v), h), 0.07, GLASS_I)
+    add(plane_xy(-2.5, 2.5, 3.2, 6.2, -4.55), 0.04, MIRROR_I, aspect=1.0)         # wall mirror
+    add(torus([0.3, 1.85, 0.6], 0.45, 0.12), 0.08, MIRROR_I)                      # chrome ornament on the table
+    add(ellipsoid([3.4, 5.2, -3.2], [0.7, 0.9, 0.7]), 0.06, WHITE_I)              # lamp shade
+    add(ellipsoid([-3.4, 0.6, -0.4], [0.6, 0.6, 0.6]), 0.04, STONE_I)             # pouffe
+
+    def floor(u, v):
+        p = np.stack([-4.7 + 9.4 * u, np.full_like(u, 0.02), -4.7 + 9.4 * v], -1)
+        return p, np.broadcast_to(np.array([0.0, 1.0, 0.0]), p.shape).copy()
+    add(floor, 0.10, WOOD_I, aspect=1.0)
+    used = sum(len(p) for p in parts)
+    rest = n_triangles - used
+    assert rest >= 2 and rest % 2 == 0, (n_triangles, used)
+    half = rest // 2
+    nu = int(np.sqrt(half))
+    while half % nu:
+        nu -= 1
+    nv = half // nu
+
+    def rug(u, v):
+        x, z = -2.8 + 6.0 * u, -1.2 + 4.2 * v
+        y = 0.06 + 0.012 * np.sin(9.0 * x) * np.sin(7.0 * z)
+        dydx = 0.012 * 9.0 * np.cos(9.0 * x) * np.sin(7.0 * z)
+        dydz = 0.012 * 7.0 * np.sin(9.0 * x) * np.cos(7.0 * z)
+        return np.stack([x, y, z], -1), np.stack([-dydx, np.ones_like(x), -dydz], -1)
+    parts.append(_grid_surface(rug, nu, nv, FABRIC_I))
+    faces = np.concatenate(parts)
+    assert len(faces) == n_triangles
+    lb, ub = _mesh_bounds(faces)
+    return faces, lb, ub, mats
 
 
 def write_obj(path, faces):

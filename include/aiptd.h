@@ -124,6 +124,20 @@ int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
 #define AIPT_TRACE_NO_BROAD_PHASE 16u /* primitives: run the exact box/sphere test of every primitive for every ray like the
                                        reference (pathtrace.cu:226-245) instead of only on the primitives whose padded
                                        world box the ray can touch; same result, for parity checks and timing */
+#define AIPT_TRACE_SORT_MATERIAL 32u /* SORT_MATERIAL true (pathtrace.cu:21, 412-417, 508-510): after the partition the surviving paths
+                                       are stably sorted by material id, exactly as the reference's thrust::sort_by_key call
+                                       orders them (its keys are the hit records of the PRE-partition array slots; a miss has
+                                       id 0), and the next bounce seeds each path's RNG with its slot after the sort.  Here the
+                                       sort is a counting sort of the 4-byte live list (the path state does not move).  Needs
+                                       AIPT_TRACE_COMPACT and at most 256 materials. */
+#define AIPT_TRACE_CACHE_FIRST_BOUNCE 64u /* CACHE_BOUNCE true (pathtrace.cu:22, 466-476): iter == 1 saves the bounce-0 hit records,
+                                       iter > 1 reuses them instead of intersecting the primary rays again.  Like the reference
+                                       (assert, :435-436) only legal without AIPT_TRACE_AA and without AIPT_TRACE_MOTION_BLUR; the
+                                       caller keeps camera and scene fixed between iter 1 and the iterations that reuse it. */
+#define AIPT_TRACE_MOTION_BLUR 128u /* MOTION_BLUR true (pathtrace.cu:27, 318-331, 442-446): before every iteration with
+                                       iter % 4 == 0 and iter < 3000 the primitives that have a velocity (Geom::vel, scene key VEL)
+                                       move by vel * 0.10 and their matrices are rebuilt; the moved primitives persist in the
+                                       context until the next aipt_scene_upload. */
 #define AIPT_TRACE_DEFAULT     (AIPT_TRACE_AA | AIPT_TRACE_COMPACT)
 
 /* pathtraceInit (pathtrace.cu:96-129), scene part: copies and re-lays-out the scene on the device.
@@ -160,7 +174,8 @@ int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n);
                                        stay split hi/lo, fp32 accumulation (2 MFMAs per product, half the weight traffic);
                                        results = the reference model run with its conv weights rounded to fp16 */
 
-/* blob: flat weight file, format in ai_path_tracer_denoiser_amd/arch.py (header + 28 x {W,b,gamma,beta,mean,var}). */
+/* blob: flat weight file, format in ai_path_tracer_denoiser_amd/arch.py (header + 28 x {W,b,gamma,beta,mean,var}).
+ * Loading weights resets the recurrent hidden state (the next AIPT_DN_HIDDEN_CARRY frame starts from zeros). */
 int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);
 /* activations for frames of height x width (both multiples of 32: five 2x pools + skip concat). */
 int aipt_denoise_configure(aipt_ctx* ctx, int height, int width);
@@ -193,7 +208,8 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
  * Starts the path trace of the NEXT frame on a second HIP stream, into the context's back G-buffer, so that it overlaps
  * the denoise of the frame being processed; the following aipt_frame with an identical (cam, iter, depth, trace_flags)
  * consumes it instead of tracing.  A different request drops the prefetch.  Results are identical to unpipelined
- * frames.  aipt_sync waits for both streams. */
+ * frames.  Only iter == 1 frames can be prefetched (planes 3-9 of later iterations live in the buffer iteration 1 wrote):
+ * other values return AIPT_E_INVALID.  aipt_sync waits for both streams. */
 int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
 /* the context-owned padded G-buffer float[10][Hp][Wp] of the last aipt_frame (device pointer) and its padded size */
 int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);

@@ -126,6 +126,7 @@ class AABB(C.Structure):          # sceneStructs.h:84 (24 B)
 assert (C.sizeof(Geom), C.sizeof(Face), C.sizeof(Material), C.sizeof(Camera), C.sizeof(AABB)) == (248, 76, 44, 84, 24)
 
 SPHERE, CUBE = 0, 1
+TRACE_AA, TRACE_COMPACT, TRACE_SORT_MATERIAL, TRACE_CACHE_FIRST_BOUNCE = 1, 2, 32, 64     # = include/aiptd.h AIPT_TRACE_*
 
 
 def _trace_lib():
@@ -157,6 +158,9 @@ def _trace_lib():
                                     C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_pathtrace_accum.restype = C.c_int
         L.orc_pathtrace_accum.argtypes = L.orc_pathtrace.argtypes + [C.c_void_p]
+        L.orc_pathtrace_ex.restype = C.c_int
+        L.orc_pathtrace_ex.argtypes = L.orc_pathtrace.argtypes[:10] + [C.c_uint] + L.orc_pathtrace.argtypes[10:] + [C.c_void_p] * 2
+        L.orc_move_geoms.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.orc_build_geom.argtypes = [C.c_void_p]
         L.orc_camera_setup.argtypes = [C.c_void_p, C.c_float]
         L.orc_camera_orbit_params.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
@@ -293,8 +297,17 @@ class OracleScene:
             fa = (Face * max(1, len(self.faces)))(*self.faces)
         return ga, ma, fa
 
-    def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True, accum=None, gbuf=None):
-        """One 1-spp frame (pathtrace.cu:422-528).  Returns (gbuf[10,Hp,W], n_live[depth+1], mat0[H*W])."""
+    def move_geoms(self, dt=0.10):
+        """moveGeom (pathtrace.cu:318-331): translate the primitives that have a velocity, rebuild their matrices."""
+        ga = (Geom * max(1, len(self.geoms)))(*self.geoms)
+        _trace_lib().orc_move_geoms(ga, len(self.geoms), C.c_float(dt))
+        self.geoms = [Geom.from_buffer_copy(bytes(ga[i])) for i in range(len(self.geoms))]
+
+    def pathtrace(self, iter=1, depth=None, pad_rows_to=None, want_mat0=True, accum=None, gbuf=None,
+                  flags=TRACE_AA | TRACE_COMPACT, cache=None):
+        """One 1-spp frame (pathtrace.cu:422-528).  Returns (gbuf[10,Hp,W], n_live[depth+1], mat0[H*W]).
+        flags: TRACE_* below (the reference's #defines, pathtrace.cu:20-26); cache: uint8[W*H*36] kept by the caller
+        across iterations for TRACE_CACHE_FIRST_BOUNCE."""
         L = _trace_lib()
         W, H = self.camera.res[0], self.camera.res[1]
         Hp = pad_rows_to or H
@@ -304,8 +317,9 @@ class OracleScene:
         n_live = np.full(depth + 1, -1, np.int32)
         mat0 = np.full(W * H, -2, np.int32)
         ga, ma, fa = self.arrays()
-        nb = L.orc_pathtrace_accum(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
-                                   self.nfaces, C.byref(self.mesh_box), iter, depth, gbuf.ctypes.data, Hp,
-                                   n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None,
-                                   accum.ctypes.data if accum is not None else None)
+        nb = L.orc_pathtrace_ex(C.byref(self.camera), ga, len(self.geoms), ma, len(self.materials), fa,
+                                self.nfaces, C.byref(self.mesh_box), iter, depth, flags, gbuf.ctypes.data, Hp,
+                                n_live.ctypes.data, mat0.ctypes.data if want_mat0 else None,
+                                accum.ctypes.data if accum is not None else None,
+                                cache.ctypes.data if cache is not None else None)
         return gbuf, n_live[:nb + 1], mat0

@@ -374,7 +374,7 @@ void orc_scatter(float* io, const float* hit, const orc_material* m, uint32_t* r
 }
 
 /* ---------------------------------------------------------------- pathtrace.cu kernels */
-static void generateRay(const orc_camera* cam, int iter, int traceDepth, int x, int y, path_t* seg) {   /* :155-182 */
+static void generateRay(const orc_camera* cam, int iter, int traceDepth, int x, int y, int aa, path_t* seg) {   /* :155-182 */
     const int index = x + (y * cam->res[0]);
     uint32_t rng = orc_seed(iter, index, 0 /* F7: uninitialised in the reference; defined as 0 */);
     const v3 view = V(cam->view[0], cam->view[1], cam->view[2]);
@@ -384,8 +384,9 @@ static void generateRay(const orc_camera* cam, int iter, int traceDepth, int x, 
     seg->color = V(1.0f, 1.0f, 1.0f);
     const float jx = orc_u01(&rng, -0.5f, 0.5f);     /* AA true (pathtrace.cu:25) */
     const float jy = orc_u01(&rng, -0.5f, 0.5f);
-    const float sx = (float)x - (float)cam->res[0] * 0.5f + jx;
-    const float sy = (float)y - (float)cam->res[1] * 0.5f + jy;
+    float sx = (float)x - (float)cam->res[0] * 0.5f;
+    float sy = (float)y - (float)cam->res[1] * 0.5f;
+    if (aa) { sx = sx + jx; sy = sy + jy; }                /* :170-180 */
     seg->direction = vnormalize(vsub(vsub(view, vscale(vscale(right, cam->pixelLength[0]), sx)),
                                      vscale(vscale(up, cam->pixelLength[1]), sy)));
     seg->pixelIndex = index;
@@ -463,38 +464,78 @@ int orc_pathtrace(const orc_camera* cam, const orc_geom* geoms, int ngeoms, cons
 /* accum: optional float[3*W*H] = the reference's dev_image (glm::vec3 per pixel, pathtrace.cu:101-102), kept by the caller
  * across iterations 1..n of a multi-sample render (image += colour each iteration, planes 0-2 = image / iter,
  * pathtrace.cu:400, 88-92); planes 3-9 are only written at iter == 1 (:295, :379). */
+int orc_pathtrace_ex(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
+                     const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth, unsigned flags,
+                     float* gbuf, int Hp, int* n_live, int* mat0, float* accum, void* cache);
+
 int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
                         const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth,
                         float* gbuf, int Hp, int* n_live, int* mat0, float* accum) {
+    return orc_pathtrace_ex(cam, geoms, ngeoms, mats, nmats, faces, nfaces, box, iter, traceDepth, 1u | 2u, gbuf, Hp,
+                            n_live, mat0, accum, NULL);
+}
+
+/* The reference's compile-time switches (pathtrace.cu:20-26) as run-time flags, same bit values as include/aiptd.h:
+ *   1  AA                 jitter the primary rays (:167-176)
+ *   2  STREAM_COMPACTION  thrust::partition after every bounce (:504-507)
+ *  32  SORT_MATERIAL      thrust::sort_by_key(dev_intersections, dev_intersections + num_paths, dev_paths, sort_cmp) (:508-510).
+ *                         As written it runs AFTER the partition with the post-partition num_paths, so the key of array slot
+ *                         j is the material id of the hit record the PRE-partition slot j holds (a miss has id 0: the records
+ *                         are memset before every computeIntersections, :478, and a miss only sets t, :283-285).  Thrust's
+ *                         sort_by_key with a user comparator is a stable merge sort (thrust/system/cuda/detail/sort.h:
+ *                         sort_by_key -> stable_sort_by_key; rocThrust likewise), so the result is deterministic: a stable
+ *                         sort of the surviving paths by those keys.  The next bounce seeds each path's RNG with its
+ *                         slot after the sort (:351).
+ *  64  CACHE_BOUNCE       iter == 1: the bounce-0 hit records are saved (:466-472); iter > 1: bounce 0 reuses them instead of
+ *                         intersecting (:473-476).  Only legal with AA off (assert :435).  cache = caller-held P * 36 bytes.
+ */
+typedef struct { int key, pos; } sort_item;
+static int sort_item_cmp(const void* a, const void* b) {
+    const sort_item* x = (const sort_item*)a; const sort_item* y = (const sort_item*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+int orc_pathtrace_ex(const orc_camera* cam, const orc_geom* geoms, int ngeoms, const orc_material* mats, int nmats,
+                     const orc_face* faces, int nfaces, const orc_aabb* box, int iter, int traceDepth, unsigned flags,
+                     float* gbuf, int Hp, int* n_live, int* mat0, float* accum, void* cache) {
     const int W = cam->res[0], H = cam->res[1];
     const int P = W * H;
     const size_t plane = (size_t)W * Hp;
+    const int aa = (flags & 1u) != 0, compact = (flags & 2u) != 0, sortmat = (flags & 32u) != 0;
+    const int use_cache = (flags & 64u) != 0 && cache != NULL;
     path_t* paths = (path_t*)malloc(sizeof(path_t) * P);
     path_t* tmp = (path_t*)malloc(sizeof(path_t) * P);
     hit_t* hits = (hit_t*)malloc(sizeof(hit_t) * P);
+    sort_item* items = sortmat ? (sort_item*)malloc(sizeof(sort_item) * P) : NULL;
     v3* image = accum ? (v3*)accum : (v3*)calloc(P, sizeof(v3));
     (void)nmats;
 #pragma omp parallel for schedule(static)
-    for (int i = 0; i < P; i++) generateRay(cam, iter, traceDepth, i % W, i / W, &paths[i]);
+    for (int i = 0; i < P; i++) generateRay(cam, iter, traceDepth, i % W, i / W, aa, &paths[i]);
 
     int depth = 0, num_paths = P, done = 0;
     while (!done) {
         n_live[depth] = num_paths;
+        if (depth == 0 && use_cache && iter > 1) {
+            memcpy(hits, cache, sizeof(hit_t) * P);                  /* :473-476 */
+        } else {
 #pragma omp parallel for schedule(dynamic, 256)
-        for (int idx = 0; idx < num_paths; idx++) {
-            v3 rawn;
-            computeIntersection(&paths[idx], geoms, ngeoms, faces, nfaces, box, &hits[idx], &rawn);
-            if (depth == 0 && iter == 1) {
-                if (mat0) mat0[paths[idx].pixelIndex] = hits[idx].t >= 0 ? hits[idx].materialId : -1;
-                if (hits[idx].t >= 0) {                              /* :295-304 */
-                    const int col = idx % W, row = idx / W;
-                    const size_t d = (size_t)(W - col - 1) + (size_t)row * W;
-                    gbuf[plane * 3 + d] = rawn.x;
-                    gbuf[plane * 4 + d] = rawn.y;
-                    gbuf[plane * 5 + d] = rawn.z;
-                    gbuf[plane * 6 + d] = hits[idx].t;
+            for (int idx = 0; idx < num_paths; idx++) {
+                v3 rawn;
+                computeIntersection(&paths[idx], geoms, ngeoms, faces, nfaces, box, &hits[idx], &rawn);
+                if (depth == 0 && iter == 1) {
+                    if (mat0) mat0[paths[idx].pixelIndex] = hits[idx].t >= 0 ? hits[idx].materialId : -1;
+                    if (hits[idx].t >= 0) {                              /* :295-304 */
+                        const int col = idx % W, row = idx / W;
+                        const size_t d = (size_t)(W - col - 1) + (size_t)row * W;
+                        gbuf[plane * 3 + d] = rawn.x;
+                        gbuf[plane * 4 + d] = rawn.y;
+                        gbuf[plane * 5 + d] = rawn.z;
+                        gbuf[plane * 6 + d] = hits[idx].t;
+                    }
                 }
             }
+            if (depth == 0 && use_cache && iter == 1) memcpy(cache, hits, sizeof(hit_t) * P);   /* :466-472 */
         }
 #pragma omp parallel for schedule(static)
         for (int idx = 0; idx < num_paths; idx++) {                  /* shadeMaterial :333-390 */
@@ -526,7 +567,7 @@ int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms
         depth++;
         /* thrust::partition (:505): survivors keep their relative order (rocThrust partition.h:617,655-657 --
          * rejected items are emitted reversed; their order is irrelevant, finalGather scatters by pixelIndex). */
-        {
+        if (compact) {
             int a = 0, b = num_paths;
             for (int i = 0; i < num_paths; i++) {
                 if (paths[i].remainingBounces > 0) tmp[a++] = paths[i];
@@ -534,6 +575,12 @@ int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms
             }
             memcpy(paths, tmp, sizeof(path_t) * num_paths);
             num_paths = a;
+        }
+        if (sortmat && num_paths > 1) {                              /* :508-510, see the flag table above */
+            for (int i = 0; i < num_paths; i++) { items[i].key = hits[i].materialId; items[i].pos = i; }
+            qsort(items, num_paths, sizeof(sort_item), sort_item_cmp);
+            for (int i = 0; i < num_paths; i++) tmp[i] = paths[items[i].pos];
+            memcpy(paths, tmp, sizeof(path_t) * num_paths);
         }
         done = (num_paths == 0 || depth == traceDepth);
     }
@@ -551,9 +598,22 @@ int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms
             gbuf[plane + d] = pix.y / fiter;
             gbuf[plane * 2 + d] = pix.z / fiter;
         }
-    free(paths); free(tmp); free(hits);
+    free(paths); free(tmp); free(hits); free(items);
     if (!accum) free(image);
     return depth;
+}
+
+/* moveGeom (pathtrace.cu:318-331), called every 4th iteration with dt = 0.10 when MOTION_BLUR (:442-446): primitives with a
+ * non-zero velocity are translated and their three matrices rebuilt (device-side buildTransformationMatrix :307-316 = the
+ * host one, utilities.cpp:45-52). */
+void orc_build_geom(orc_geom* g);
+void orc_move_geoms(orc_geom* geoms, int ngeoms, float dt) {
+    for (int i = 0; i < ngeoms; i++) {
+        orc_geom* g = &geoms[i];
+        if (g->vel[0] == 0.0f && g->vel[1] == 0.0f && g->vel[2] == 0.0f) continue;
+        for (int a = 0; a < 3; a++) g->translation[a] += g->vel[a] * dt;
+        orc_build_geom(g);
+    }
 }
 
 /* ---------------------------------------------------------------- host-side scene math */

@@ -22,6 +22,20 @@ def to_api_scene(sc):
     return geoms, mats, faces, box, cam
 
 
+def add_materials(sc, records):
+    """append 44-byte material records (synth.material(...)) to an OracleScene; returns the id of the first one"""
+    import oracle
+    first = len(sc.materials)
+    for r in records:
+        sc.materials.append(oracle.Material.from_buffer_copy(r))
+    return first
+
+
+def bits(a):
+    """float32 array -> uint32 bit patterns (bit-exact comparison, NaN- and signed-zero-safe)"""
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
 def add_stone_material(sc):
     """append the diffuse 'stone' material of the mesh scenes (RGB .75 .7 .6) and return its id"""
     import oracle
@@ -31,15 +45,23 @@ def add_stone_material(sc):
     return len(sc.materials) - 1
 
 
-def gpu_trace(ctx, sc, depth, rows=None, stride=None, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0):
+def gpu_trace(ctx, sc, depth, rows=None, stride=None, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0, iters=1, upload=True,
+              each_iter=None):
+    """Upload sc (unless upload=False), run iterations 1..iters into one G-buffer; returns (gbuf, n_live, mat0) of the last
+    iteration.  each_iter(it, gbuf_numpy) is called after every iteration when given."""
     import torch
     geoms, mats, faces, box, cam = to_api_scene(sc)
     W, H = cam.resolution[0], cam.resolution[1]
     rows = rows or H
     stride = stride or W
-    ctx.pathtrace_init(geoms, mats, faces, box, W, H)
+    if upload:
+        ctx.pathtrace_init(geoms, mats, faces, box, W, H)
     gbuf = torch.zeros(10, rows, stride, device="cuda")
     torch.cuda.synchronize()          # the zero fill runs on torch's stream, the trace on the context's non-blocking stream
-    ctx.pathtrace(cam, 1, depth, gbuf, flags)
-    ctx.sync()
-    return gbuf.cpu().numpy(), ctx.live_counts(depth), ctx.first_hit_materials(W * H)
+    for it in range(1, iters + 1):
+        ctx.pathtrace(cam, it, depth, gbuf, flags)
+        ctx.sync()
+        if each_iter is not None:
+            each_iter(it, gbuf.cpu().numpy())
+    mat0 = ctx.first_hit_materials(W * H) if (flags & api.TRACE_RECORD_MAT0) else None
+    return gbuf.cpu().numpy(), ctx.live_counts(depth), mat0

@@ -44,7 +44,8 @@ def test_against_reference_goldens(ctx, golden_dir, name):
     for j in range(nfr):
         ref = g["out"][j]
         err = np.abs(outs[j] - ref).max()
-        assert err <= TOL * max(1.0, float(np.abs(ref).max()) / 8), (name, j, err)
+        print(f"{name} frame {j}: max abs err vs the reference model {err:.2e} (|ref|max {np.abs(ref).max():.1f})")
+        assert err <= TOL, (name, j, err)                     # north_star: 1e-3 max abs per channel, absolute
     import torch
     for lvl, shp in enumerate(arch.hidden_shapes(H, W)):
         h = torch.empty(*shp, device="cuda")
@@ -130,18 +131,58 @@ def test_hidden_checkpoint_resume(ctx):
     c2.close()
 
 
-def test_full_size_1280x736_properties(ctx):
-    """BASELINE.json configs[1] denoiser size: properties that need no oracle run."""
-    import torch
+@pytest.mark.parametrize("bn_batch", [True, False])
+def test_full_size_1280x736_against_oracle(ctx, bn_batch):
+    """BASELINE.json configs[1]/[2]/[3] denoiser size (1280x720 padded to 736 rows), the bench's weights, two frames with the
+    hidden state carried: 1e-3 max abs against the CPU oracle, plus run-to-run equality (the BN sums are fp64 atomics of
+    fp32 partials: exact, hence order-independent) and the carry/reset property."""
+    from oracle import DenoiseOracle
     H, W = 736, 1280
     blob = synth.make_blob(565)
     frames = [synth.make_gbuffer(H, W, 1, j) for j in range(2)]
-    a = _run_gpu(ctx, blob, frames, H, W, True, True)
-    b = _run_gpu(ctx, blob, frames, H, W, True, True)
-    assert all(np.isfinite(o).all() for o in a)
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])          # deterministic (no atomics in the stats)
-    r = _run_gpu(ctx, blob, frames, H, W, True, False)
+    a = _run_gpu(ctx, blob, frames, H, W, bn_batch, True)
+    orc = DenoiseOracle(blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, bn_batch, j > 0)
+        err = np.abs(a[j] - ref).max()
+        print(f"736x1280 bn_batch={bn_batch} frame {j}: max abs err {err:.2e} (|ref|max {np.abs(ref).max():.1f})")
+        assert err <= TOL, (bn_batch, j, err)
+    b = _run_gpu(ctx, blob, frames, H, W, bn_batch, True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    r = _run_gpu(ctx, blob, frames, H, W, bn_batch, False)
     assert np.array_equal(r[0], a[0]) and not np.array_equal(r[1], a[1])      # carry only matters from frame 1 on
+
+
+def test_fp16_weights_full_size_1920x1088_against_oracle(ctx):
+    """BASELINE.json configs[4] denoiser: 1920x1080 (padded to 1088 rows), fp16 conv weights: the oracle on the fp16-rounded
+    blob, 1e-3 max abs."""
+    import oracle
+    H, W = 1088, 1920
+    blob = synth.make_blob(565)
+    params = arch.unpack_blob(blob)
+    for p in params.values():
+        p["w"] = p["w"].astype(np.float16).astype(np.float32)
+    orc = oracle.DenoiseOracle(arch.pack_blob(params), H, W)
+    frames = [synth.make_gbuffer(H, W, 3, j) for j in range(2)]
+    got = _run_gpu(ctx, blob, frames, H, W, True, True, impl=api.DN_IMPL_MFMA_F16W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, True, j > 0)
+        err = np.abs(got[j] - ref).max()
+        print(f"1088x1920 fp16 weights frame {j}: max abs err {err:.2e} (|ref|max {np.abs(ref).max():.1f})")
+        assert err <= TOL, (j, err)
+
+
+def test_weight_reload_resets_the_recurrent_state(ctx):
+    import torch
+    H, W = 64, 64
+    frames = [synth.make_gbuffer(H, W, 9, j) for j in range(2)]
+    _run_gpu(ctx, synth.make_blob(3), frames, H, W, True, True)          # leaves a valid hidden state
+    ctx.load_weights(synth.make_blob(4))
+    y = torch.empty(3, H, W, device="cuda")
+    ctx.denoise(torch.from_numpy(frames[0]).cuda(), y, bn_batch=True, carry=True)   # carry requested, but the reload reset it
+    ctx.sync()
+    fresh = _run_gpu(ctx, synth.make_blob(4), frames[:1], H, W, True, False)
+    assert np.array_equal(y.cpu().numpy(), fresh[0])
 
 
 def test_rejects_bad_sizes_and_missing_weights():

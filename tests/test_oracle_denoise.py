@@ -32,8 +32,7 @@ def test_oracle_matches_reference_goldens(golden_dir, name):
         y = orc.forward(x, bn_batch=bool(batch), carry=(j > 0))
         ref = g["out"][j]
         err = np.abs(y - ref).max()
-        scale = max(1.0, float(np.abs(ref).max()))
-        assert err <= TOL * scale, (name, j, err)
+        assert err <= 1e-3, (name, j, err)                       # north_star's bar, absolute (measured: 2e-5 .. 3.6e-4)
     for lvl, shp in enumerate(arch.hidden_shapes(H, W)):
         h = orc.hidden(lvl).astype(np.float64)
         flat = h.reshape(shp[0], -1)

@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaiptd.so")
+LIB_PATH = os.environ.get("AIPT_LIB") or os.path.join(_HERE, "libaiptd.so")   # AIPT_LIB: kernel-variant builds (tools/)
 
 # flags (include/aiptd.h)
 TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0, TRACE_BRUTE_FORCE, TRACE_NO_BROAD_PHASE = 1, 2, 4, 8, 16
@@ -75,8 +75,16 @@ ABI = [
     ("aipt_timer_stop", C.c_int, [_P, C.POINTER(C.c_float)]),
     ("aipt_scene_upload", C.c_int, [_P, _P, C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     ("aipt_scene_free", C.c_int, [_P]),
+    ("aipt_scene_pack", C.c_int, [_P, C.c_int, _P, C.c_int, _P, C.c_int, _P, C.POINTER(_P), C.POINTER(C.c_size_t), C.c_char_p,
+                                  C.c_size_t]),
+    ("aipt_blob_free", None, [_P]),
+    ("aipt_scene_upload_packed", C.c_int, [_P, _P, C.c_size_t]),
+    ("aipt_trace_profile_begin", C.c_int, [_P, C.c_int, C.c_int]),
+    ("aipt_trace_profile_end", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    ("aipt_trace_kernel_name", C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
     ("aipt_trace_configure", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_trace", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, _P, C.c_int, C.c_int]),
+    ("aipt_debug_trace_stats", C.c_int, [_P, _P, C.c_int]),
     ("aipt_trace_live_counts", C.c_int, [_P, _P, C.c_int]),
     ("aipt_trace_first_hit_materials", C.c_int, [_P, _P, C.c_int]),
     ("aipt_denoise_load_weights", C.c_int, [_P, _P, C.c_size_t]),
@@ -138,6 +146,31 @@ def lib():
             fn.argtypes = args
         _LIB = L
     return _LIB
+
+
+def scene_pack(geoms, materials, faces=(), mesh_box=None) -> bytes:
+    """aipt_scene_pack: validate, build the mesh BVH once (host only) and return the relocatable scene blob that
+    Context.pathtrace_init_packed uploads -- the unit rank 0 broadcasts to the other GPUs."""
+    L = lib()
+    ga = (Geom * max(1, len(geoms)))(*geoms)
+    ma = (Material * max(1, len(materials)))(*materials)
+    if isinstance(faces, np.ndarray):
+        assert faces.dtype.itemsize == 76
+        keep = np.ascontiguousarray(faces)
+        fa = keep.ctypes.data_as(_P)
+    else:
+        fa = (Face * max(1, len(faces)))(*faces)
+    box = mesh_box if mesh_box is not None else AABB()
+    out, n = _P(), C.c_size_t()
+    err = C.create_string_buffer(256)
+    rc = L.aipt_scene_pack(ga, len(geoms), ma, len(materials), fa if len(faces) else None, len(faces),
+                           C.byref(box) if len(faces) else None, C.byref(out), C.byref(n), err, 256)
+    if rc:
+        raise AiptError(f"aipt_scene_pack failed ({rc}): {err.value.decode()}")
+    try:
+        return C.string_at(out.value, n.value)
+    finally:
+        L.aipt_blob_free(out)
 
 
 class Scene:
@@ -260,6 +293,27 @@ class Context:
                                          C.byref(box) if len(faces) else None))
         if width is not None:
             self._ck(lib().aipt_trace_configure(self._h, width, height))
+
+    def pathtrace_init_packed(self, blob: bytes, width=None, height=None):
+        """pathtraceInit from a packed scene (scene_pack): copies only, the BVH inside the blob is not rebuilt."""
+        self._ck(lib().aipt_scene_upload_packed(self._h, blob, len(blob)))
+        if width is not None:
+            self._ck(lib().aipt_trace_configure(self._h, width, height))
+
+    def trace_profile_begin(self, max_calls: int, every: int = 1):
+        self._ck(lib().aipt_trace_profile_begin(self._h, max_calls, every))
+
+    def trace_profile_end(self, nbounces: int):
+        """-> (summed ms of every bounce launch [nbounces], number of recorded traces)"""
+        ms = np.zeros(nbounces, np.float64)
+        n = C.c_int()
+        self._ck(lib().aipt_trace_profile_end(self._h, ms.ctypes.data, nbounces, C.byref(n)))
+        return ms, n.value
+
+    def trace_kernel_name(self, bounce: int) -> str:
+        name = C.create_string_buffer(64)
+        self._ck(lib().aipt_trace_kernel_name(self._h, bounce, name, 64))
+        return name.value.decode()
 
     def pathtrace_init_scene(self, scene: "Scene", width=None, height=None):
         """pathtraceInit(Scene*) from a parsed Scene."""

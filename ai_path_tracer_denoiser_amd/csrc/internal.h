@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -57,17 +59,26 @@ void set_global_error(const char* msg);
 #define AIPT_CHECK_CTX(ctx) \
     do { if (!(ctx)) return AIPT_E_INVALID; } while (0)
 
-// BVH node (bvh.cpp): the padded boxes and references of both children; ref >= 0: inner node index, ref < 0:
+// 4-wide BVH node (bvh.cpp), 64 bytes = four 16-byte loads: quantisation frame (origin p, per-axis scale 2^(e-127)), the
+// 8-bit child boxes (byte k of qlo[a] / qhi[a] = child k on axis a; decoded lo = fma(q, scale, p), always enclosing the padded
+// fp32 box) and the child references: >= 0 inner node index, BVH_EMPTY = no child, otherwise a leaf
 // -(first_leaf_face * 8 + count) - 1.  Root = node 0.
-constexpr int BVH_LEAF_FACES = 2;
-constexpr int BVH_MAX_DEPTH = 48;    // deepest tree the traversal stack (LDS, depth x 1 KB per workgroup) is allowed to need
-struct BvhNode {
-    float lo0[3]; int ref0;
-    float hi0[3]; int ref1;
-    float lo1[3]; int pad0;
-    float hi1[3]; int pad1;
+constexpr int BVH_LEAF_FACES = 4;
+constexpr int BVH_EMPTY = INT32_MIN;
+constexpr int BVH_MAX_STACK = 72;    // most stack entries per lane the traversal may need (LDS: entries x 1 KB per workgroup)
+struct Bvh4Node {
+    float p[3]; uint32_t exps;       // exps = ex | ey << 8 | ez << 16 | nchildren << 24
+    uint32_t qlo[3], qhi[3];
+    int ref[4];
+    uint32_t pad[2];
 };
-int build_bvh(const aipt_face* faces, int nfaces, std::vector<BvhNode>& nodes, std::vector<int>& leaf_faces);   // tree depth, -1: too deep
+static_assert(sizeof(Bvh4Node) == 64, "Bvh4Node");
+// leaf triangle record, 48 bytes = three 16-byte loads: v0, e1 = v1 - v0, e2 = v2 - v0 (the fp32 subtractions
+// glm::intersectRayTriangle starts with), the face's index in the caller's array
+struct TriRec { float v0[3], e1[3], e2[3]; int face; int pad[2]; };
+static_assert(sizeof(TriRec) == 48, "TriRec");
+// returns the traversal-stack bound (entries per lane), -1: the mesh needs more than BVH_MAX_STACK
+int build_bvh4(const aipt_face* faces, int nfaces, std::vector<Bvh4Node>& nodes, std::vector<int>& leaf_faces);
 
 // aipt_trace on an explicit stream; orders itself after the previous trace when that ran on another stream
 int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags, float* d_gbuf,

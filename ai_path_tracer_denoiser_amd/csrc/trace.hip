@@ -5,16 +5,18 @@
 // (generateRayFromCamera :155-182, computeIntersections :200-306, shadeMaterial :333-390, thrust::partition :505,
 // finalGather :393-402, copy_data :81-94); the execution plan is not:
 //
-//  * Path state is SoA in HBM (9 float planes + 1 int plane, 40 B/path) and NEVER MOVES: path i is pixel i for the
-//    whole frame, so every access is a fully coalesced wave64 load/store.
+//  * Path state is three float4 planes in HBM (48 B/path: origin+dx | dy dz + colour rg | colour b + remaining bounces) and
+//    NEVER MOVES: path i is pixel i for the whole frame.  A bounce loads and stores it with three 16-byte accesses per lane
+//    (what bounds this kernel is the number of per-lane vector-memory accesses, see bvh.cpp and DESIGN.md).
 //  * Stream compaction is logical.  thrust::partition keeps survivors in their original relative order, so the index
-//    a live path has after compaction -- which seeds its RNG, pathtrace.cu:351 -- is its RANK among live paths in pixel
-//    order.  Each bounce kernel recomputes that rank from per-workgroup live counts written by the previous bounce
-//    (block prefix) + wave64 __ballot/__popcll (in-block prefix).  No scan kernel, no scatter pass, no host sync per
-//    bounce (the reference syncs twice per bounce, :483/:505).
+//    a live path has after compaction -- which seeds its RNG, pathtrace.cu:351 -- is its RANK among live paths in array
+//    order.  trace_compact turns the per-slot alive flags of a bounce into the next bounce's live list (workgroup prefix +
+//    wave64 __ballot/__popcll prefix).  No scan kernel, no host sync per bounce (the reference syncs twice per bounce).
 //  * One kernel per bounce fuses ray generation (bounce 0), nearest-hit search, shading/scatter, the G-buffer
 //    writes (planes 3-9, already h-flipped) and finalGather+copy_data: a path deposits its colour into planes 0-2
 //    the moment its remainingBounces reaches 0 (light, miss, or depth exhausted -- SURVEY F9).
+//  * Mesh: a 4-wide BVH with 8-bit child boxes (64-byte nodes) walked front to back on a per-lane LDS stack, 48-byte leaf
+//    triangle records, the winning face fetched once after the walk (bvh.cpp).
 //
 // Arithmetic is plain IEEE fp32 (this file is compiled with -ffp-contract=off, correctly rounded divide/sqrt), in the
 // statement order of the reference/GLM sources, so the output matches the CPU restatement used by the tests bit for
@@ -34,54 +36,65 @@ struct DevGeom {          // one primitive; matrices column-major (glm::mat4)
     float lo[3], hi[3];   // padded world-space box around the primitive (broad phase only, never decides a hit)
 };
 constexpr int MAXG_LDS = 32;   // scenes with up to this many primitives use the per-lane candidate loop
+constexpr int MAXM_LDS = 32;   // materials kept in LDS (more: read from HBM)
 struct DevFace {          // Face, sceneStructs.h:40
     float v[3][3], n[3][3];
     int materialid;
 };
+struct alignas(16) DevFaceP { DevFace f; int pad; };   // 80 bytes: five 16-byte loads (leaf order, fetched once per ray)
+static_assert(sizeof(DevFaceP) == 80, "DevFaceP");
+
+constexpr int MAX_DEPTH = 64;
 
 struct TraceState {
     DevGeom* d_geoms = nullptr; int ngeoms = 0;
     aipt_material* d_mats = nullptr; int nmats = 0;
-    DevFace* d_faces = nullptr; int nfaces = 0;
-    int bvh_depth = 0;
-    BvhNode* d_nodes = nullptr; int nnodes = 0;     // threaded BVH over the faces (bvh.cpp)
-    DevFace* d_lfaces = nullptr;                    // faces in leaf order
-    int* d_lidx = nullptr;                          // their original indices (tie-break + parity with the index-ordered loop)
+    DevFace* d_faces = nullptr; int nfaces = 0;      // caller's order (AIPT_TRACE_BRUTE_FORCE)
+    int stack_need = 0;
+    Bvh4Node* d_nodes = nullptr; int nnodes = 0;     // 4-wide BVH over the faces (bvh.cpp)
+    TriRec* d_tris = nullptr;                        // leaf-ordered triangle records
+    DevFaceP* d_lfaces = nullptr;                    // leaf-ordered full faces
     aipt_aabb box{};
     bool have_scene = false;
     int W = 0, H = 0, P = 0, nblk = 0;
-    float* d_state = nullptr;     // [10][P]: ox oy oz dx dy dz cr cg cb rem(int bits)
-    int* d_cnt[2] = {nullptr, nullptr};   // per-workgroup live counts, ping-pong between bounces
-    int* d_live[2] = {nullptr, nullptr};  // live-path index lists, ping-pong between bounces
+    float4* d_state = nullptr;    // [3][P]: (ox oy oz dx) (dy dz cr cg) (cb rem . .)
+    int* d_cnt = nullptr;         // per-workgroup live counts of the last bounce
+    int* d_alive = nullptr;       // [P] per array slot: does the path survive the bounce?
+    int* d_live[3] = {nullptr, nullptr, nullptr};  // live-path index lists (third one: AIPT_TRACE_SORT_MATERIAL)
     int* d_nlive = nullptr;       // [MAX_DEPTH+1]
     int* d_mat0 = nullptr;        // [P]
     float* d_image = nullptr;     // [3][P] radiance accumulated over iterations 1..n (dev_image, pathtrace.cu:101), h-flipped
     float* d_cache = nullptr;     // [8][P] bounce-0 hit records of iteration 1 (AIPT_TRACE_CACHE_FIRST_BOUNCE): t, material, P, raw N
-    int* d_live3 = nullptr;       // third live list (AIPT_TRACE_SORT_MATERIAL: compact -> sort -> next bounce)
     int* d_sortkey = nullptr;     // [P] material id of the hit found in array slot t at the current bounce (0 = miss)
     int* d_hist = nullptr;        // [nkeys][nblk] counting-sort histogram / bases
+    int* d_stack_ovf = nullptr; int ovf_entries = 0;   // traversal-stack overflow, [entries][P]
     int hist_keys = 0;
     bool cache_valid = false;
     std::vector<aipt_geom> h_geoms;   // host copy for AIPT_TRACE_MOTION_BLUR (moveGeom, pathtrace.cu:318-331)
     int last_depth = 0;
     bool mat0_valid = false;
+    // HIP-event timing of the bounce launches (aipt_trace_profile_*)
+    int prof_max = 0, prof_calls = 0, prof_every = 1, prof_seen = 0;
+    std::vector<hipEvent_t> prof_ev;              // [call][bounce][2]
+    char kname[2][40] = {};                       // instantiation that ran bounce 0 / the later bounces in the last trace
 };
-constexpr int MAX_DEPTH = 64;
 
 struct TraceParams {
     aipt_camera cam;
     int iter, trace_depth, bounce;
     uint32_t flags;
     int W, H, P;
-    float* st;
+    float4* st;
     const DevGeom* geoms; int ngeoms;
-    const aipt_material* mats;
+    const aipt_material* mats; int nmats;
     const DevFace* faces; int nfaces;
-    const BvhNode* nodes; int nnodes;
-    const DevFace* lfaces; const int* lidx;
+    const Bvh4Node* nodes;
+    const TriRec* tris;
+    const DevFaceP* lfaces;
     aipt_aabb box;
     float* gbuf; size_t plane; int stride;
-    const int* cnt_in; int* cnt_out;
+    int* cnt;                    // per-workgroup live counts (bounce -> compact)
+    int* alive;                  // per array slot: survives this bounce (bounce -> compact)
     int* n_live;
     int* mat0;
     float* image;
@@ -91,6 +104,7 @@ struct TraceParams {
     int* sortkey;                   // AIPT_TRACE_SORT_MATERIAL: material id of the hit in array slot t (0 = miss)
     int* hist; int nkeys, nblk;
     const int* sort_in; int* sort_out;
+    int* stack_ovf;                 // [stack bound - STACK_LDS][P] traversal-stack overflow (see WalkStack)
 };
 
 // ---------------------------------------------------------------------------------------------- vector helpers
@@ -345,24 +359,204 @@ __device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hi
     pcolor = vmul(pcolor, color);
 }
 
+// glm::intersectRayTriangle (gtx/intersect.inl:37-74) on a leaf record: e1, e2 are the subtractions the function starts with,
+// done once on the host in fp32.  Returns the hit distance (baryPosition.z) or -1; same operations in the same order as
+// triangleTest above, so the value is the one the full test of that face returns.
+__device__ __forceinline__ float triHitT(v3 v0, v3 e1, v3 e2, v3 orig, v3 dir) {
+    const v3 p = vcross(dir, e2);
+    const float a = vdot(e1, p);
+    if (a < FLT_EPSILON) return -1.0f;
+    const float ff = 1.0f / a;
+    const v3 s = vsub(orig, v0);
+    const float bx = ff * vdot(s, p);
+    if (bx < 0.0f) return -1.0f;
+    if (bx > 1.0f) return -1.0f;
+    const v3 q = vcross(s, e1);
+    const float by = ff * vdot(dir, q);
+    if (by < 0.0f) return -1.0f;
+    if (by + bx > 1.0f) return -1.0f;
+    const float bz = ff * vdot(e2, q);
+    if (!(bz >= 0.0f)) return -1.0f;
+    return bz;
+}
+
+// -DAIPT_TRACE_STATS: walk statistics for tools/trace_stats.py (lane-level node visits and triangle tests, wave-level loop
+// trips); compiled out of the product build.
+#ifdef AIPT_TRACE_STATS
+__device__ unsigned long long g_trace_stats[16];
+#define STAT_ADD(k, v) atomicAdd(&g_trace_stats[k], (unsigned long long)(v))
+#define STAT_WAVE(k) do { if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&g_trace_stats[k], 1ull); } while (0)
+#else
+#define STAT_ADD(k, v) do {} while (0)
+#define STAT_WAVE(k) do {} while (0)
+#endif
+
+__device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
+__device__ __forceinline__ void cas(float& ka, int& ra, float& kb, int& rb) {      // compare-exchange: (ka, ra) <= (kb, rb)
+    const bool sw = ka > kb;
+    const float tk = sw ? kb : ka, uk = sw ? ka : kb;
+    const int tr = sw ? rb : ra, ur = sw ? ra : rb;
+    ka = tk; kb = uk; ra = tr; rb = ur;
+}
+
+// glm::intersectRayTriangle on a leaf record, straight-line: every comparison of the reference is evaluated and combined
+// at the end (same operations, same operands, same value as triHitT / the reference's early returns; a lone wave pays more
+// for a divergent branch than for the few operations it would skip).
+__device__ __forceinline__ float triHitT_flat(v3 v0, v3 e1, v3 e2, v3 orig, v3 dir) {
+    const v3 p = vcross(dir, e2);
+    const float a = vdot(e1, p);
+    const float ff = 1.0f / a;
+    const v3 s = vsub(orig, v0);
+    const float bx = ff * vdot(s, p);
+    const v3 q = vcross(s, e1);
+    const float by = ff * vdot(dir, q);
+    const float bz = ff * vdot(e2, q);
+    const bool miss = (a < FLT_EPSILON) | (bx < 0.0f) | (bx > 1.0f) | (by < 0.0f) | (by + bx > 1.0f) | !(bz >= 0.0f);
+    return miss ? -1.0f : bz;
+}
+
+// Per-lane traversal stack: the first STACK_LDS entries live in LDS ([entry][thread]: conflict-free), deeper entries -- the
+// builder's bound can reach BVH_MAX_STACK, the atrium never exceeds 14 and goes past 8 on 0.03 % of its node visits -- in a
+// global overflow area ([entry][array slot]).  A full-size LDS stack would cap the kernel at 3 waves per SIMD.
+constexpr int STACK_LDS = 8;
+struct WalkStack {
+    int* lds; int* ovf; size_t ostride; int sp;
+    __device__ __forceinline__ void push(int v) {
+        if (sp < STACK_LDS) lds[sp * 256] = v; else ovf[(size_t)(sp - STACK_LDS) * ostride] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop() {
+        sp--;
+        return sp < STACK_LDS ? lds[sp * 256] : ovf[(size_t)(sp - STACK_LDS) * ostride];
+    }
+};
+
+// Nearest mesh hit through the 4-wide BVH.  Same result as the reference's loop over all faces in index order
+// (pathtrace.cu:258-269): the reference's triangle test on the candidate faces; among equal distances the face with the lowest
+// index wins and a face never replaces a primitive hit at equal distance (strict t_min > t in the reference's loop).
+// Walk: "while-while" -- descend through inner nodes until the lane holds a leaf (or nothing), then test the leaf's
+// triangles (loaded two at a time: one memory round trip per pair); the nearer children are visited first, the others wait on
+// the per-lane stack.  Box test per child: the ray's direction signs pick the entry and the exit plane of every axis once per
+// node (on the packed 4-child words), then t = fma(q, scale/d, (p - o)/d) on the 8-bit coordinate q, max3 / min3 -- 14 VALU
+// operations per child; the fma's error corresponds to ~1e-6 in space, far inside the boxes' padding.
+__device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot) {
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const bool negx = __float_as_uint(ix) >> 31, negy = __float_as_uint(iy) >> 31, negz = __float_as_uint(iz) >> 31;
+    const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
+    const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
+    int best_face = -1;
+    int cur = 0;
+    st.sp = 0;
+    constexpr int DONE = BVH_EMPTY;
+#ifdef AIPT_TRACE_STATS
+    int my_visits = 0;
+#define STAT_MINE() my_visits++
+#else
+#define STAT_MINE() do {} while (0)
+#endif
+    while (true) {
+        while (cur >= 0) {
+            STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
+            const uint4* nd = nodes + (unsigned)cur * 4u;
+            const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+            const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
+                        sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
+            const float bx = (__uint_as_float(w0.x) - o.x) * ix, by = (__uint_as_float(w0.y) - o.y) * iy,
+                        bz = (__uint_as_float(w0.z) - o.z) * iz;
+            // entry / exit planes of the four children, per axis (qlo = w1.xyz, qhi = w1.w, w2.x, w2.y)
+            const uint32_t nx = negx ? w1.w : w1.x, fx = negx ? w1.x : w1.w;
+            const uint32_t ny = negy ? w2.x : w1.y, fy = negy ? w1.y : w2.x;
+            const uint32_t nz = negz ? w2.y : w1.z, fz = negz ? w1.z : w2.y;
+            float key[4];
+            int ref[4] = {(int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float n = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nx, k), sx, bx), __builtin_fmaf(ubyte_f(ny, k), sy, by)),
+                                      __builtin_fmaf(ubyte_f(nz, k), sz, bz));
+                const float f = fminf(fminf(__builtin_fmaf(ubyte_f(fx, k), sx, bx), __builtin_fmaf(ubyte_f(fy, k), sy, by)),
+                                      __builtin_fmaf(ubyte_f(fz, k), sz, bz));
+                const bool h = ref[k] != BVH_EMPTY && !(f < 0.0f || n > f || n > t_min);      // NaN -> visit
+                key[k] = h ? fmaxf(n, -FLT_MAX) : INFINITY;                                    // a NaN key of a hit sorts first
+            }
+            cas(key[0], ref[0], key[1], ref[1]);
+            cas(key[2], ref[2], key[3], ref[3]);
+            cas(key[0], ref[0], key[2], ref[2]);
+            cas(key[1], ref[1], key[3], ref[3]);
+            cas(key[1], ref[1], key[2], ref[2]);
+            if (__builtin_expect(st.sp + 3 > STACK_LDS, 0)) {   // rare: some of the pushes may go to the overflow area
+                if (key[3] < INFINITY) st.push(ref[3]);
+                if (key[2] < INFINITY) st.push(ref[2]);
+                if (key[1] < INFINITY) st.push(ref[1]);
+            } else {                                            // farthest first: the stack pops the nearest
+                if (key[3] < INFINITY) st.lds[st.sp++ * 256] = ref[3];
+                if (key[2] < INFINITY) st.lds[st.sp++ * 256] = ref[2];
+                if (key[1] < INFINITY) st.lds[st.sp++ * 256] = ref[1];
+            }
+#ifdef AIPT_TRACE_STATS
+            atomicMax(&g_trace_stats[6], (unsigned long long)st.sp);
+            if (st.sp > 8) STAT_ADD(7, 1);
+            if (st.sp > 12) STAT_ADD(15, 1);
+#endif
+            if (key[0] < INFINITY) cur = ref[0];
+            else cur = st.sp ? st.pop() : DONE;
+        }
+        if (cur == DONE) break;
+        {
+            const int v = -cur - 1, first = v >> 3, cnt = v & 7;
+            STAT_ADD(2, cnt); STAT_ADD(4, 1); STAT_WAVE(3);
+            for (int k = 0; k < cnt; k += 2) {
+                const bool two = k + 1 < cnt;
+                const uint4* tr = tris + (unsigned)(first + k) * 3u;
+                const uint4* tr2 = two ? tr + 3 : tr;           // odd count: the second test repeats the first (no effect)
+                const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
+                const uint4 q0 = tr2[0], q1 = tr2[1], q2 = tr2[2];
+                const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                              V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                              V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), o, d);
+                const int fa = (int)r2.y;
+                if (ta > 0.0f && (t_min > ta || (t_min == ta && best_face >= 0 && fa < best_face))) {
+                    t_min = ta; best_face = fa; best_slot = first + k;
+                }
+                const float tb = triHitT_flat(V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                              V(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)),
+                                              V(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)), o, d);
+                const int fb = (int)q2.y;
+                if (tb > 0.0f && (t_min > tb || (t_min == tb && best_face >= 0 && fb < best_face))) {
+                    t_min = tb; best_face = fb; best_slot = first + k + (two ? 1 : 0);
+                }
+            }
+        }
+        cur = st.sp ? st.pop() : DONE;
+        if (cur == DONE) break;
+    }
+#ifdef AIPT_TRACE_STATS
+    atomicMax(&g_trace_stats[5], (unsigned long long)my_visits);
+    const int bucket = my_visits <= 4 ? 8 : my_visits <= 8 ? 9 : my_visits <= 16 ? 10 : my_visits <= 32 ? 11 : my_visits <= 64 ? 12 : my_visits <= 128 ? 13 : 14;
+    atomicAdd(&g_trace_stats[bucket], 1ull);
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------- the bounce kernel
 // MESH = false drops the triangle path (and its LDS traversal stack) from the instantiation used for primitive-only scenes.
+#ifndef AIPT_TRACE_OCC
+#define AIPT_TRACE_OCC 1
+#endif
 template <bool FIRST, bool MESH>
-__global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
+__global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
     __shared__ int s_wave[4];
-    __shared__ DevGeom s_geoms[MAXG_LDS];
-    extern __shared__ int s_stack[];                            // MESH: [tree depth + 1][thread] far children still to visit
+    // dynamic LDS: [MESH: STACK_LDS x 256 stack words][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)], sized by the launch
+    extern __shared__ __attribute__((aligned(16))) int s_dyn[];
+    int* s_stack = s_dyn;
+    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0));
+    aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = p.P;
-    float* ox = p.st;            float* oy = p.st + (size_t)P;      float* oz = p.st + (size_t)2 * P;
-    float* dx = p.st + (size_t)3 * P; float* dy = p.st + (size_t)4 * P; float* dz = p.st + (size_t)5 * P;
-    float* cr = p.st + (size_t)6 * P; float* cg = p.st + (size_t)7 * P; float* cb = p.st + (size_t)8 * P;
-    int* remp = reinterpret_cast<int*>(p.st + (size_t)9 * P);
+    float4* S0 = p.st; float4* S1 = p.st + (size_t)P; float4* S2 = p.st + (size_t)2 * P;
 
     // ---- which path does this thread advance, and at which index would thrust::partition have left it?
     // Bounce 0: thread t = pixel t.  Later bounces walk the LIVE LIST written by trace_compact: entry t is the pixel of the
-    // t-th live path in pixel order, so t is exactly the compacted array index that seeds the RNG (pathtrace.cu:351) --
-    // every wave is full of live paths and the state planes are gathered/scattered through the (monotonic) pixel index.
+    // t-th live path in array order, so t is exactly the compacted array index that seeds the RNG (pathtrace.cu:351) --
+    // every wave is full of live paths and the state planes are gathered/scattered through the pixel index.
     int i, idx, rem = 0;
     bool alive;
     const int t = blockIdx.x * 256 + tid;
@@ -371,22 +565,26 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     } else {
         const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
         if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
-            if (tid == 0) p.cnt_out[blockIdx.x] = 0;
+            if (tid == 0) p.cnt[blockIdx.x] = 0;
             return;
         }
         alive = t < n;
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
-        if (alive) rem = remp[i];
     }
 
-    // primitives into LDS: the candidate loop below indexes them per lane
+    // primitives and materials into LDS: the candidate loop and the shader index them per lane
     const bool broad = p.ngeoms <= MAXG_LDS && !(p.flags & AIPT_TRACE_NO_BROAD_PHASE);
+    const bool mats_lds = p.nmats <= MAXM_LDS;
     if (broad) {
         const int nw = p.ngeoms * (int)(sizeof(DevGeom) / 4);
         for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_geoms)[k] = reinterpret_cast<const int*>(p.geoms)[k];
-        __syncthreads();
     }
+    if (mats_lds) {
+        const int nw = p.nmats * (int)(sizeof(aipt_material) / 4);
+        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
+    }
+    __syncthreads();
 
     bool alive_after = false;
     if (alive) {
@@ -410,9 +608,11 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             d = vnormalize(vsub(vsub(view, vscale(vscale(right, p.cam.pixelLength[0]), sx)),
                                 vscale(vscale(up, p.cam.pixelLength[1]), sy)));
         } else {
-            o = V(ox[i], oy[i], oz[i]);
-            d = V(dx[i], dy[i], dz[i]);
-            col = V(cr[i], cg[i], cb[i]);
+            const float4 a = S0[i], b = S1[i], c = S2[i];
+            o = V(a.x, a.y, a.z);
+            d = V(a.w, b.x, b.y);
+            col = V(b.z, b.w, c.x);
+            rem = __float_as_int(c.y);
         }
 
         // ---- computeIntersections :200-306 (primitives first, then the mesh; strict t_min > t keeps the first of equals)
@@ -425,8 +625,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             t_min = c[0]; materialid = __float_as_int(c[(size_t)P]);
             hitP = V(c[(size_t)2 * P], c[(size_t)3 * P], c[(size_t)4 * P]);
             normal = V(c[(size_t)5 * P], c[(size_t)6 * P], c[(size_t)7 * P]);
-        } else
-        if (broad) {
+        } else if (broad) {
             // broad phase over all primitives (wave-uniform loop, scalar loads), then the exact tests on this lane's
             // candidates only, in index order (so "the first of equal distances wins" as in the reference's loop): a
             // wave runs max-over-lanes(candidates) exact tests instead of ngeoms
@@ -463,48 +662,21 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
                     if (t > 0.0f && t_min > t) { t_min = t; materialid = p.faces[fi].materialid; hitP = tp; normal = tn; }
                 }
             } else {
-                // BVH, front to back: same triangle test on the candidate faces.  The index-ordered loop keeps the FIRST face
-                // among equal distances and never lets a face replace a primitive at equal distance; best_face
-                // reproduces exactly that, so the result is the brute-force result.
-                const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-                int best_face = -1;
-                int sp = 0, cur = 0;                           // reference being visited: >= 0 inner node, < 0 leaf
-                while (true) {
-                    if (cur >= 0) {
-                        const BvhNode nd = p.nodes[cur];
-                        const float a1 = (nd.lo0[0] - o.x) * ix, a2 = (nd.hi0[0] - o.x) * ix;
-                        const float a3 = (nd.lo0[1] - o.y) * iy, a4 = (nd.hi0[1] - o.y) * iy;
-                        const float a5 = (nd.lo0[2] - o.z) * iz, a6 = (nd.hi0[2] - o.z) * iz;
-                        const float b1 = (nd.lo1[0] - o.x) * ix, b2 = (nd.hi1[0] - o.x) * ix;
-                        const float b3 = (nd.lo1[1] - o.y) * iy, b4 = (nd.hi1[1] - o.y) * iy;
-                        const float b5 = (nd.lo1[2] - o.z) * iz, b6 = (nd.hi1[2] - o.z) * iz;
-                        const float n0 = fmaxf(fmaxf(fminf(a1, a2), fminf(a3, a4)), fminf(a5, a6));
-                        const float f0 = fminf(fminf(fmaxf(a1, a2), fmaxf(a3, a4)), fmaxf(a5, a6));
-                        const float n1 = fmaxf(fmaxf(fminf(b1, b2), fminf(b3, b4)), fminf(b5, b6));
-                        const float f1 = fminf(fminf(fmaxf(b1, b2), fmaxf(b3, b4)), fmaxf(b5, b6));
-                        const bool h0 = !(f0 < 0.0f || n0 > f0 || n0 > t_min);      // NaN -> visit
-                        const bool h1 = !(f1 < 0.0f || n1 > f1 || n1 > t_min);
-                        if (h0 && h1) {                                            // nearer child first, the other one waits
-                            const bool first0 = n0 <= n1;
-                            s_stack[sp++ * 256 + tid] = first0 ? nd.ref1 : nd.ref0;   // depth-bounded by the builder
-                            cur = first0 ? nd.ref0 : nd.ref1;
-                            continue;
-                        }
-                        if (h0 || h1) { cur = h0 ? nd.ref0 : nd.ref1; continue; }
-                    } else {
-                        const int v = -cur - 1, first = v >> 3, cnt = v & 7;
-                        for (int k = 0; k < cnt; k++) {
-                            v3 tp, tn;
-                            const float t = triangleTest(p.lfaces[first + k], o, d, tp, tn);
-                            const int fi = p.lidx[first + k];
-                            if (t > 0.0f && (t_min > t || (t_min == t && best_face >= 0 && fi < best_face))) {
-                                t_min = t; materialid = p.lfaces[first + k].materialid; hitP = tp; normal = tn;
-                                best_face = fi;
-                            }
-                        }
-                    }
-                    if (sp == 0) break;
-                    cur = s_stack[--sp * 256 + tid];
+                int best_slot = -1;
+                WalkStack st{s_stack + tid, p.stack_ovf + t, (size_t)p.P, 0};
+                bvh4_nearest(p, o, d, st, t_min, best_slot);
+                if (best_slot >= 0) {
+                    // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
+                    const uint4* fp = reinterpret_cast<const uint4*>(p.lfaces + best_slot);
+                    const uint4 q0 = fp[0], q1 = fp[1], q2 = fp[2], q3 = fp[3], q4 = fp[4];
+                    DevFace f;
+                    uint32_t* fw = reinterpret_cast<uint32_t*>(&f);
+                    fw[0] = q0.x; fw[1] = q0.y; fw[2] = q0.z; fw[3] = q0.w; fw[4] = q1.x; fw[5] = q1.y; fw[6] = q1.z; fw[7] = q1.w;
+                    fw[8] = q2.x; fw[9] = q2.y; fw[10] = q2.z; fw[11] = q2.w; fw[12] = q3.x; fw[13] = q3.y; fw[14] = q3.z; fw[15] = q3.w;
+                    fw[16] = q4.x; fw[17] = q4.y; fw[18] = q4.z;
+                    v3 tp, tn;
+                    const float t = triangleTest(f, o, d, tp, tn);
+                    t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
                 }
             }
         }
@@ -515,7 +687,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             c[(size_t)2 * P] = hitP.x; c[(size_t)3 * P] = hitP.y; c[(size_t)4 * P] = hitP.z;
             c[(size_t)5 * P] = normal.x; c[(size_t)6 * P] = normal.y; c[(size_t)7 * P] = normal.z;
         }
-        if (p.sortkey) p.sortkey[FIRST ? i : t] = hit ? materialid : 0;   // the hit record's materialId (memset 0, :478)
+        if (p.sortkey) p.sortkey[t] = hit ? materialid : 0;        // the hit record's materialId (memset 0, :478)
         const v3 surfN = vnormalize(normal);
         const int x = i % p.W, y = i / p.W;
         const size_t gd = (size_t)y * p.stride + (size_t)(p.W - x - 1);         // h-flipped destination (:297-299)
@@ -524,7 +696,7 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
         int new_rem;
         if (hit) {
             uint32_t rng = make_seed(p.iter, idx, rem);
-            const aipt_material m = p.mats[materialid];
+            const aipt_material m = mats_lds ? s_mats[materialid] : p.mats[materialid];
             if (m.emittance > 0.0f) {
                 new_rem = 0;
                 col = vscale(vmul(col, V(m.color[0], m.color[1], m.color[2])), m.emittance);
@@ -560,14 +732,13 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
             gb[0] = ax / fiter;
             gb[p.plane] = ay / fiter;
             gb[p.plane * 2] = az / fiter;
-            remp[i] = 0;
         } else {
-            ox[i] = o.x; oy[i] = o.y; oz[i] = o.z;
-            dx[i] = d.x; dy[i] = d.y; dz[i] = d.z;
-            cr[i] = col.x; cg[i] = col.y; cb[i] = col.z;
-            remp[i] = new_rem;
+            S0[i] = make_float4(o.x, o.y, o.z, d.x);
+            S1[i] = make_float4(d.y, d.z, col.x, col.y);
+            S2[i] = make_float4(col.z, __int_as_float(new_rem), 0.0f, 0.0f);
             alive_after = true;
         }
+        p.alive[t] = alive_after ? 1 : 0;
     }
 
     // ---- live count of this workgroup for the next bounce
@@ -576,14 +747,14 @@ __global__ __launch_bounds__(256) void trace_bounce(const TraceParams p) {
     __syncthreads();
     if (tid == 0) {
         const int c = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
-        p.cnt_out[blockIdx.x] = c;
+        p.cnt[blockIdx.x] = c;
         if (c) atomicAdd(&p.n_live[p.bounce + 1], c);
     }
 }
 
 // Stable stream compaction of the live list (the wave64 ballot/popcount analogue of thrust::partition, pathtrace.cu:505):
-// entry t of the input list survives iff its path still has bounces left; survivors keep their order.  Output position =
-// (live counts of the lower workgroups, written by trace_bounce) + (ballot prefix inside the workgroup).
+// array slot t of the bounce that just ran survives iff its path still has bounces left; survivors keep their order.
+// Output position = (live counts of the lower workgroups, written by trace_bounce) + (ballot prefix inside the workgroup).
 __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     __shared__ int s_wave[4];
     __shared__ int s_base;
@@ -591,15 +762,14 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     const int n = p.bounce == 0 ? p.P : p.n_live[p.bounce];
     if ((int)(blockIdx.x * 256) >= n) return;
     const int t = blockIdx.x * 256 + tid;
-    const int* remp = reinterpret_cast<const int*>(p.st + (size_t)9 * p.P);
     int i = 0;
     bool alive = false;
     if (t < n) {
         i = p.live_in ? p.live_in[t] : t;
-        alive = remp[i] != 0;
+        alive = p.alive[t] != 0;
     }
     int part = 0;
-    for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt_out[j];
+    for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt[j];
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     const unsigned long long mask = __ballot(alive);
     if (lane == 0) s_wave[wave] = part;
@@ -672,12 +842,31 @@ __global__ __launch_bounds__(256) void trace_sort_scatter(const TraceParams p) {
     }
 }
 
+static void free_scene(TraceState* s) {
+    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_lfaces);
+    s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
+    s->d_nodes = nullptr; s->d_tris = nullptr; s->d_lfaces = nullptr; s->nnodes = 0; s->cache_valid = false;
+}
+static void free_frame(TraceState* s) {
+    hipFree(s->d_state); hipFree(s->d_cnt); hipFree(s->d_alive); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
+    for (int*& l : s->d_live) { hipFree(l); l = nullptr; }
+    hipFree(s->d_cache); hipFree(s->d_sortkey); hipFree(s->d_hist); hipFree(s->d_stack_ovf);
+    s->d_stack_ovf = nullptr; s->ovf_entries = 0;
+    s->d_state = nullptr; s->d_cnt = nullptr; s->d_alive = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
+    s->d_cache = nullptr; s->d_sortkey = nullptr; s->d_hist = nullptr; s->hist_keys = 0; s->cache_valid = false;
+}
+static void free_trace_profile(TraceState* s) {
+    for (hipEvent_t e : s->prof_ev) if (e) hipEventDestroy(e);
+    s->prof_ev.clear();
+    s->prof_max = 0; s->prof_calls = 0; s->prof_seen = 0;
+}
+
 void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
-    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image); hipFree(s->d_live[0]); hipFree(s->d_live[1]);
-    hipFree(s->d_cache); hipFree(s->d_live3); hipFree(s->d_sortkey); hipFree(s->d_hist);
+    free_scene(s);
+    free_frame(s);
+    free_trace_profile(s);
     delete s;
     ctx->trace = nullptr;
 }
@@ -715,68 +904,170 @@ static DevGeom make_dev_geom(const aipt_geom& g) {
     return d;
 }
 
+// ---- packed scene: everything a context needs to trace, relocatable, built once (rank 0) and broadcast to the other GPUs.
+// Layout: PackHeader, then 16-byte aligned sections in this order: geoms (aipt_geom), materials (aipt_material), faces
+// (aipt_face, caller's order), BVH nodes (Bvh4Node), leaf triangle records (TriRec; TriRec::face = index into faces).
+struct PackHeader {
+    char magic[8];                 // "AIPTSB02"
+    uint32_t ngeoms, nmats, nfaces, nnodes;
+    int32_t stack_need;
+    uint32_t reserved[3];
+    aipt_aabb box;
+    uint64_t total_bytes;
+};
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+struct PackView {
+    const PackHeader* h;
+    const aipt_geom* geoms; const aipt_material* mats; const aipt_face* faces; const Bvh4Node* nodes; const TriRec* tris;
+};
+static size_t pack_layout(uint32_t ng, uint32_t nm, uint32_t nf, uint32_t nn, size_t off[5]) {
+    size_t o = align16(sizeof(PackHeader));
+    off[0] = o; o = align16(o + sizeof(aipt_geom) * (size_t)ng);
+    off[1] = o; o = align16(o + sizeof(aipt_material) * (size_t)nm);
+    off[2] = o; o = align16(o + sizeof(aipt_face) * (size_t)nf);
+    off[3] = o; o = align16(o + sizeof(Bvh4Node) * (size_t)nn);
+    off[4] = o; o = align16(o + sizeof(TriRec) * (size_t)nf);
+    return o;
+}
+static bool pack_view(const void* blob, size_t bytes, PackView& v) {
+    if (!blob || bytes < sizeof(PackHeader)) return false;
+    const PackHeader* h = (const PackHeader*)blob;
+    if (memcmp(h->magic, "AIPTSB02", 8)) return false;
+    size_t off[5];
+    const size_t total = pack_layout(h->ngeoms, h->nmats, h->nfaces, h->nnodes, off);
+    if (total != bytes || h->total_bytes != bytes) return false;
+    const char* b = (const char*)blob;
+    v.h = h;
+    v.geoms = (const aipt_geom*)(b + off[0]); v.mats = (const aipt_material*)(b + off[1]); v.faces = (const aipt_face*)(b + off[2]);
+    v.nodes = (const Bvh4Node*)(b + off[3]); v.tris = (const TriRec*)(b + off[4]);
+    return true;
+}
+
 }  // namespace aipt
 
 using namespace aipt;
 
 extern "C" {
 
-int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
-                      const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box) {
-    AIPT_CHECK_CTX(ctx);
+int aipt_scene_pack(const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
+                    const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box, void** blob_out, size_t* bytes_out,
+                    char* err, size_t errlen) {
+    auto bad = [&](int code, const char* fmt, int a, int b, int c) {
+        if (err && errlen) snprintf(err, errlen, fmt, a, b, c);
+        return code;
+    };
+    if (!blob_out || !bytes_out) return AIPT_E_INVALID;
+    *blob_out = nullptr; *bytes_out = 0;
     if (ngeoms < 0 || nmaterials <= 0 || nfaces < 0 || (ngeoms && !geoms) || !materials || (nfaces && (!faces || !mesh_box)))
-        return fail(ctx, AIPT_E_INVALID, "aipt_scene_upload: bad arguments (%d geoms, %d materials, %d faces)", ngeoms,
-                    nmaterials, nfaces);
+        return bad(AIPT_E_INVALID, "aipt_scene_pack: bad arguments (%d geoms, %d materials, %d faces)", ngeoms, nmaterials, nfaces);
     for (int i = 0; i < ngeoms; i++)
         if (geoms[i].materialid < 0 || geoms[i].materialid >= nmaterials)
-            return fail(ctx, AIPT_E_INVALID, "geom %d: material %d of %d", i, geoms[i].materialid, nmaterials);
+            return bad(AIPT_E_INVALID, "geom %d: material %d of %d", i, geoms[i].materialid, nmaterials);
     for (int i = 0; i < nfaces; i++)
         if (faces[i].materialid < 0 || faces[i].materialid >= nmaterials)
-            return fail(ctx, AIPT_E_INVALID, "face %d: material %d of %d", i, faces[i].materialid, nmaterials);
+            return bad(AIPT_E_INVALID, "face %d: material %d of %d", i, faces[i].materialid, nmaterials);
+    std::vector<Bvh4Node> nodes;
+    std::vector<int> lidx;
+    int need = 0;
+    if (nfaces) {
+        need = build_bvh4(faces, nfaces, nodes, lidx);
+        if (need < 0) return bad(AIPT_E_INVALID, "aipt_scene_pack: mesh of %d faces needs a deeper traversal stack than %d entries%c", nfaces, BVH_MAX_STACK, ' ');
+    }
+    size_t off[5];
+    const size_t total = pack_layout(ngeoms, nmaterials, nfaces, (uint32_t)nodes.size(), off);
+    char* b = (char*)calloc(1, total);
+    if (!b) return bad(AIPT_E_NOMEM, "aipt_scene_pack: out of memory (%d geoms, %d materials, %d faces)", ngeoms, nmaterials, nfaces);
+    PackHeader* h = (PackHeader*)b;
+    memcpy(h->magic, "AIPTSB02", 8);
+    h->ngeoms = ngeoms; h->nmats = nmaterials; h->nfaces = nfaces; h->nnodes = (uint32_t)nodes.size();
+    h->stack_need = need;
+    if (nfaces) h->box = *mesh_box;
+    h->total_bytes = total;
+    if (ngeoms) memcpy(b + off[0], geoms, sizeof(aipt_geom) * (size_t)ngeoms);
+    memcpy(b + off[1], materials, sizeof(aipt_material) * (size_t)nmaterials);
+    if (nfaces) {
+        memcpy(b + off[2], faces, sizeof(aipt_face) * (size_t)nfaces);
+        memcpy(b + off[3], nodes.data(), sizeof(Bvh4Node) * nodes.size());
+        TriRec* tr = (TriRec*)(b + off[4]);
+        for (int k = 0; k < nfaces; k++) {
+            const aipt_face& f = faces[lidx[k]];
+            for (int a = 0; a < 3; a++) {
+                tr[k].v0[a] = f.v[0][a];
+                tr[k].e1[a] = f.v[1][a] - f.v[0][a];         // intersect.inl:44-45, the same fp32 subtraction
+                tr[k].e2[a] = f.v[2][a] - f.v[0][a];
+            }
+            tr[k].face = lidx[k];
+        }
+    }
+    *blob_out = b; *bytes_out = total;
+    return AIPT_OK;
+}
+
+void aipt_blob_free(void* blob) { free(blob); }
+
+int aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes) {
+    AIPT_CHECK_CTX(ctx);
+    PackView v;
+    if (!pack_view(blob, bytes, v)) return fail(ctx, AIPT_E_FORMAT, "aipt_scene_upload_packed: not a packed scene (%zu bytes)", bytes);
+    const int ngeoms = (int)v.h->ngeoms, nmats = (int)v.h->nmats, nfaces = (int)v.h->nfaces, nnodes = (int)v.h->nnodes;
+    if (nmats <= 0 || (nfaces && (!nnodes || v.h->stack_need < 0 || v.h->stack_need > BVH_MAX_STACK)))
+        return fail(ctx, AIPT_E_FORMAT, "aipt_scene_upload_packed: inconsistent header");
+    for (int i = 0; i < ngeoms; i++)
+        if (v.geoms[i].materialid < 0 || v.geoms[i].materialid >= nmats) return fail(ctx, AIPT_E_FORMAT, "packed scene: geom %d material", i);
+    for (int k = 0; k < nfaces; k++)
+        if (v.tris[k].face < 0 || v.tris[k].face >= nfaces || v.faces[k].materialid < 0 || v.faces[k].materialid >= nmats)
+            return fail(ctx, AIPT_E_FORMAT, "packed scene: face record %d", k);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
-    s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
-    s->d_nodes = nullptr; s->d_lfaces = nullptr; s->d_lidx = nullptr; s->nnodes = 0;
+    free_scene(s);
     std::vector<DevGeom> dg(ngeoms);
-    for (int i = 0; i < ngeoms; i++) dg[i] = make_dev_geom(geoms[i]);
-    s->h_geoms.assign(geoms, geoms + ngeoms);
+    for (int i = 0; i < ngeoms; i++) dg[i] = make_dev_geom(v.geoms[i]);
+    s->h_geoms.assign(v.geoms, v.geoms + ngeoms);
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_geoms, sizeof(DevGeom) * (ngeoms ? ngeoms : 1)));
     if (ngeoms) AIPT_HIP(ctx, hipMemcpy(s->d_geoms, dg.data(), sizeof(DevGeom) * ngeoms, hipMemcpyHostToDevice));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_mats, sizeof(aipt_material) * nmaterials));
-    AIPT_HIP(ctx, hipMemcpy(s->d_mats, materials, sizeof(aipt_material) * nmaterials, hipMemcpyHostToDevice));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_mats, sizeof(aipt_material) * nmats));
+    AIPT_HIP(ctx, hipMemcpy(s->d_mats, v.mats, sizeof(aipt_material) * nmats, hipMemcpyHostToDevice));
     static_assert(sizeof(DevFace) == sizeof(aipt_face), "face layout");
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_faces, sizeof(DevFace) * (nfaces ? nfaces : 1)));
-    if (nfaces) AIPT_HIP(ctx, hipMemcpy(s->d_faces, faces, sizeof(DevFace) * nfaces, hipMemcpyHostToDevice));
-    if (nfaces) s->box = *mesh_box; else memset(&s->box, 0, sizeof(s->box));
     if (nfaces) {
-        std::vector<BvhNode> nodes;
-        std::vector<int> lidx;
-        s->bvh_depth = build_bvh(faces, nfaces, nodes, lidx);
-        if (s->bvh_depth < 0) return fail(ctx, AIPT_E_INVALID, "aipt_scene_upload: mesh of %d faces is too deep for the traversal stack", nfaces);
-        std::vector<DevFace> lf(lidx.size());
-        for (size_t i = 0; i < lidx.size(); i++) memcpy(&lf[i], &faces[lidx[i]], sizeof(DevFace));
-        AIPT_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(BvhNode) * nodes.size()));
-        AIPT_HIP(ctx, hipMalloc((void**)&s->d_lfaces, sizeof(DevFace) * lf.size()));
-        AIPT_HIP(ctx, hipMalloc((void**)&s->d_lidx, sizeof(int) * lidx.size()));
-        AIPT_HIP(ctx, hipMemcpy(s->d_nodes, nodes.data(), sizeof(BvhNode) * nodes.size(), hipMemcpyHostToDevice));
-        AIPT_HIP(ctx, hipMemcpy(s->d_lfaces, lf.data(), sizeof(DevFace) * lf.size(), hipMemcpyHostToDevice));
-        AIPT_HIP(ctx, hipMemcpy(s->d_lidx, lidx.data(), sizeof(int) * lidx.size(), hipMemcpyHostToDevice));
-        s->nnodes = (int)nodes.size();
+        AIPT_HIP(ctx, hipMemcpy(s->d_faces, v.faces, sizeof(DevFace) * nfaces, hipMemcpyHostToDevice));
+        s->box = v.h->box;
+        std::vector<DevFaceP> lf(nfaces);
+        for (int k = 0; k < nfaces; k++) { memcpy(&lf[k].f, &v.faces[v.tris[k].face], sizeof(DevFace)); lf[k].pad = 0; }
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_nodes, sizeof(Bvh4Node) * nnodes));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_tris, sizeof(TriRec) * nfaces));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_lfaces, sizeof(DevFaceP) * nfaces));
+        AIPT_HIP(ctx, hipMemcpy(s->d_nodes, v.nodes, sizeof(Bvh4Node) * nnodes, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(s->d_tris, v.tris, sizeof(TriRec) * nfaces, hipMemcpyHostToDevice));
+        AIPT_HIP(ctx, hipMemcpy(s->d_lfaces, lf.data(), sizeof(DevFaceP) * nfaces, hipMemcpyHostToDevice));
+        s->nnodes = nnodes;
+    } else {
+        memset(&s->box, 0, sizeof(s->box));
     }
-    s->ngeoms = ngeoms; s->nmats = nmaterials; s->nfaces = nfaces;
+    s->stack_need = v.h->stack_need;
+    s->ngeoms = ngeoms; s->nmats = nmats; s->nfaces = nfaces;
     s->have_scene = true; s->cache_valid = false;
     return AIPT_OK;
+}
+
+int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
+                      const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box) {
+    AIPT_CHECK_CTX(ctx);
+    void* blob = nullptr;
+    size_t bytes = 0;
+    char err[256] = "";
+    int rc = aipt_scene_pack(geoms, ngeoms, materials, nmaterials, faces, nfaces, mesh_box, &blob, &bytes, err, sizeof(err));
+    if (rc) return fail(ctx, rc, "%s", err[0] ? err : "aipt_scene_upload: bad arguments");
+    rc = aipt_scene_upload_packed(ctx, blob, bytes);
+    aipt_blob_free(blob);
+    return rc;
 }
 
 int aipt_scene_free(aipt_ctx* ctx) {
     AIPT_CHECK_CTX(ctx);
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
-    TraceState* s = tstate(ctx);
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_lfaces); hipFree(s->d_lidx);
-    s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
-    s->d_nodes = nullptr; s->d_lfaces = nullptr; s->d_lidx = nullptr; s->nnodes = 0;
+    free_scene(tstate(ctx));
     return AIPT_OK;
 }
 
@@ -788,16 +1079,11 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
     if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
-    hipFree(s->d_state); hipFree(s->d_cnt[0]); hipFree(s->d_cnt[1]); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
-    hipFree(s->d_live[0]); hipFree(s->d_live[1]);
-    hipFree(s->d_cache); hipFree(s->d_live3); hipFree(s->d_sortkey); hipFree(s->d_hist);
-    s->d_cache = nullptr; s->d_live3 = nullptr; s->d_sortkey = nullptr; s->d_hist = nullptr; s->hist_keys = 0;
-    s->d_live[0] = s->d_live[1] = nullptr;
-    s->d_state = nullptr; s->d_cnt[0] = s->d_cnt[1] = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
+    free_frame(s);
     const int P = width * height, nblk = (P + 255) / 256;
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float) * 10 * (size_t)P));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt[0], sizeof(int) * nblk));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt[1], sizeof(int) * nblk));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float4) * 3 * (size_t)P));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt, sizeof(int) * nblk));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_alive, sizeof(int) * (size_t)P));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * (size_t)P));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * (size_t)P));
@@ -839,7 +1125,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     if (cache && iter > 1 && !s->cache_valid)
         return fail(ctx, AIPT_E_STATE, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE at iter %d without a cached iter 1", iter);
     if (sortmat) {
-        if (!s->d_live3) AIPT_HIP(ctx, hipMalloc((void**)&s->d_live3, sizeof(int) * (size_t)s->P));
+        if (!s->d_live[2]) AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[2], sizeof(int) * (size_t)s->P));
         if (!s->d_sortkey) AIPT_HIP(ctx, hipMalloc((void**)&s->d_sortkey, sizeof(int) * (size_t)s->P));
         if (s->hist_keys < s->nmats) {
             AIPT_HIP(ctx, hipStreamSynchronize(st));
@@ -847,6 +1133,13 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
             AIPT_HIP(ctx, hipMalloc((void**)&s->d_hist, sizeof(int) * (size_t)s->nmats * s->nblk));
             s->hist_keys = s->nmats;
         }
+    }
+    const int ovf_need = s->nfaces && s->stack_need > STACK_LDS ? s->stack_need - STACK_LDS : 0;
+    if (ovf_need > s->ovf_entries) {
+        AIPT_HIP(ctx, hipStreamSynchronize(st));
+        hipFree(s->d_stack_ovf); s->d_stack_ovf = nullptr; s->ovf_entries = 0;
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_stack_ovf, sizeof(int) * (size_t)ovf_need * s->P));
+        s->ovf_entries = ovf_need;
     }
     if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
     if (blur && !(iter % 4) && iter < 3000) {                   // moveGeom, pathtrace.cu:442-446 (dt = 0.10)
@@ -868,10 +1161,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     p.cam = *cam; p.iter = iter; p.trace_depth = depth; p.flags = flags;
     p.W = s->W; p.H = s->H; p.P = s->P;
     p.st = s->d_state;
-    p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats;
+    p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats; p.nmats = s->nmats;
     p.faces = s->d_faces; p.nfaces = s->nfaces; p.box = s->box;
-    p.nodes = s->d_nodes; p.nnodes = s->nnodes; p.lfaces = s->d_lfaces; p.lidx = s->d_lidx;
+    p.nodes = s->d_nodes; p.tris = s->d_tris; p.lfaces = s->d_lfaces;
     p.gbuf = d_gbuf; p.plane = (size_t)gbuf_rows * gbuf_stride; p.stride = gbuf_stride;
+    p.cnt = s->d_cnt; p.alive = s->d_alive;
     p.n_live = s->d_nlive;
     p.mat0 = (flags & AIPT_TRACE_RECORD_MAT0) ? s->d_mat0 : nullptr;
     p.image = s->d_image;
@@ -879,28 +1173,33 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     p.sortkey = sortmat ? s->d_sortkey : nullptr;
     p.hist = s->d_hist; p.nkeys = s->nmats; p.nblk = s->nblk;
     p.sort_in = nullptr; p.sort_out = nullptr;
+    p.stack_ovf = s->d_stack_ovf;
+    const bool prof = s->prof_max && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), st));
-    int* lists[3] = {s->d_live[0], s->d_live[1], s->d_live3};
+    const bool mesh = s->nfaces > 0;
+    const size_t lds_scene = (s->ngeoms <= MAXG_LDS ? sizeof(DevGeom) * s->ngeoms : 0) + (s->nmats <= MAXM_LDS ? sizeof(aipt_material) * s->nmats : 0);
+    const size_t stack_bytes = (mesh ? (size_t)STACK_LDS * 256 * sizeof(int) : 0) + lds_scene;     // dynamic LDS of the bounce kernels
+    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s>", mesh ? "true" : "false");
+    snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s>", mesh ? "true" : "false");
     int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
-        p.cnt_in = nullptr;
-        p.cnt_out = s->d_cnt[0];
-        p.live_in = cur < 0 ? nullptr : lists[cur];
+        p.live_in = cur < 0 ? nullptr : s->d_live[cur];
         const int nxt = cur < 0 ? 0 : (cur + 1) % (sortmat ? 3 : 2);
-        p.live_out = lists[nxt];
-        const bool mesh = s->nfaces > 0;
-        const size_t stack_bytes = mesh ? (size_t)(s->bvh_depth + 1) * 256 * sizeof(int) : 0;
+        p.live_out = s->d_live[nxt];
+        hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
+        if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
         if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
-        else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(s->nblk), dim3(256), 0, st, p);
+        else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(s->nblk), dim3(256), lds_scene, st, p);
         else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
-        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(s->nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(s->nblk), dim3(256), lds_scene, st, p);
+        if (pev) AIPT_HIP(ctx, hipEventRecord(pev[1], st));
         if (b + 1 < depth) {
             hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
             cur = nxt;
             if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)
                 const int srt = (cur + 1) % 3;
-                p.sort_in = lists[cur]; p.sort_out = lists[srt];
+                p.sort_in = s->d_live[cur]; p.sort_out = s->d_live[srt];
                 hipLaunchKernelGGL(trace_sort_hist, dim3(s->nblk), dim3(256), 0, st, p);
                 hipLaunchKernelGGL(trace_sort_scan, dim3(1), dim3(1024), 0, st, p);
                 hipLaunchKernelGGL(trace_sort_scatter, dim3(s->nblk), dim3(256), 0, st, p);
@@ -909,6 +1208,10 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
         }
     }
     if (cache && iter == 1) s->cache_valid = true;
+    if (s->prof_max) {
+        if (prof) s->prof_calls++;
+        s->prof_seen++;
+    }
     AIPT_HIP(ctx, hipGetLastError());
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
     ctx->last_trace_stream = st;
@@ -918,6 +1221,60 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
 }
 }  // namespace aipt
 }  // extern "C++"
+
+int aipt_trace_profile_begin(aipt_ctx* ctx, int max_calls, int every) {
+    AIPT_CHECK_CTX(ctx);
+    if (max_calls < 1 || max_calls > 4096 || every < 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace_profile_begin: max_calls %d, every %d", max_calls, every);
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    TraceState* s = tstate(ctx);
+    free_trace_profile(s);
+    s->prof_ev.resize((size_t)max_calls * MAX_DEPTH * 2, nullptr);
+    for (hipEvent_t& e : s->prof_ev) AIPT_HIP(ctx, hipEventCreate(&e));
+    s->prof_max = max_calls; s->prof_every = every;
+    return AIPT_OK;
+}
+
+int aipt_trace_profile_end(aipt_ctx* ctx, double* sum_ms_per_bounce, int nbounces, int* calls) {
+    AIPT_CHECK_CTX(ctx);
+    TraceState* s = tstate(ctx);
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    if (sum_ms_per_bounce) {
+        for (int b = 0; b < nbounces; b++) sum_ms_per_bounce[b] = 0.0;
+        for (int c = 0; c < s->prof_calls; c++)
+            for (int b = 0; b < nbounces && b < s->last_depth && b < MAX_DEPTH; b++) {
+                float ms = 0;
+                AIPT_HIP(ctx, hipEventElapsedTime(&ms, s->prof_ev[((size_t)c * MAX_DEPTH + b) * 2], s->prof_ev[((size_t)c * MAX_DEPTH + b) * 2 + 1]));
+                sum_ms_per_bounce[b] += ms;
+            }
+    }
+    if (calls) *calls = s->prof_calls;
+    free_trace_profile(s);
+    return AIPT_OK;
+}
+
+int aipt_trace_kernel_name(aipt_ctx* ctx, int bounce, char* kernel, size_t kernel_len) {
+    AIPT_CHECK_CTX(ctx);
+    TraceState* s = tstate(ctx);
+    if (!s->last_depth) return fail(ctx, AIPT_E_STATE, "aipt_trace_kernel_name: no trace has run");
+    if (!kernel || !kernel_len) return fail(ctx, AIPT_E_INVALID, "aipt_trace_kernel_name: NULL buffer");
+    strncpy(kernel, s->kname[bounce > 0 ? 1 : 0], kernel_len - 1);
+    kernel[kernel_len - 1] = 0;
+    return AIPT_OK;
+}
+
+int aipt_debug_trace_stats(aipt_ctx* ctx, unsigned long long* out8, int reset) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+#ifdef AIPT_TRACE_STATS
+    if (out8) AIPT_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_trace_stats), 128));
+    if (reset) { unsigned long long z[16] = {0}; AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, 128)); }
+    return AIPT_OK;
+#else
+    (void)reset;
+    if (out8) memset(out8, 0, 128);
+    return fail(ctx, AIPT_E_STATE, "aipt_debug_trace_stats: library built without -DAIPT_TRACE_STATS");
+#endif
+}
 
 int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n) {
     AIPT_CHECK_CTX(ctx);

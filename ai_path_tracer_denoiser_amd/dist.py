@@ -16,33 +16,63 @@ import numpy as np
 
 from . import api
 
-SCENE_MAGIC = b"AIPTSC01"
+SCENE_MAGIC = b"AIPTSB02"
+_HDR = struct.Struct("<8s4Ii3I6fQ")          # PackHeader of csrc/trace.hip (72 bytes)
+NODE_DTYPE = np.dtype([("p", np.float32, 3), ("exps", np.uint32), ("qlo", np.uint32, 3), ("qhi", np.uint32, 3),
+                       ("ref", np.int32, 4), ("pad", np.uint32, 2)])                          # Bvh4Node, 64 B
+TRI_DTYPE = np.dtype([("v0", np.float32, 3), ("e1", np.float32, 3), ("e2", np.float32, 3), ("face", np.int32),
+                      ("pad", np.int32, 2)])                                                  # TriRec, 48 B
+assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48 and _HDR.size == 72
 
 
 def pack_scene(geoms, materials, faces, mesh_box) -> bytes:
-    """Scene blob: magic, counts, then the raw POD arrays (layouts of include/aiptd.h)."""
-    out = [SCENE_MAGIC, struct.pack("<III", len(geoms), len(materials), len(faces))]
-    out += [bytes(g) for g in geoms]
-    out += [bytes(m) for m in materials]
-    out += [bytes(f) for f in faces]
-    out.append(bytes(mesh_box) if mesh_box is not None else bytes(C.sizeof(api.AABB)))
-    return b"".join(out)
+    """The packed scene blob of aipt_scene_pack: validated scene + the mesh BVH, built once on the host (rank 0)."""
+    return api.scene_pack(geoms, materials, faces, mesh_box)
+
+
+def _align16(v):
+    return (v + 15) & ~15
+
+
+def scene_sections(blob: bytes):
+    """Header fields and section offsets of a packed scene (layout: csrc/trace.hip PackHeader)."""
+    magic, ng, nm, nf, nn, need, _, _, _, *rest = _HDR.unpack_from(blob, 0)
+    assert magic == SCENE_MAGIC, "bad scene blob"
+    box, total = rest[:6], rest[6]
+    assert total == len(blob)
+    off = {}
+    o = _align16(_HDR.size)
+    for name, sz in (("geoms", 248 * ng), ("materials", 44 * nm), ("faces", 76 * nf), ("nodes", 64 * nn), ("tris", 48 * nf)):
+        off[name] = o
+        o = _align16(o + sz)
+    assert o == len(blob)
+    return dict(ngeoms=ng, nmaterials=nm, nfaces=nf, nnodes=nn, stack_need=need, box=box), off
 
 
 def unpack_scene(blob: bytes):
-    assert blob[:8] == SCENE_MAGIC, "bad scene blob"
-    ng, nm, nf = struct.unpack_from("<III", blob, 8)
-    off = 20
-    def take(cls, n):
-        nonlocal off
+    """-> (geoms, materials, faces, mesh_box) as api structs (inspection and tests; contexts take the blob as it is)."""
+    h, off = scene_sections(blob)
+
+    def take(cls, o, n):
         sz = C.sizeof(cls)
-        items = [cls.from_buffer_copy(blob[off + i * sz: off + (i + 1) * sz]) for i in range(n)]
-        off += n * sz
-        return items
-    geoms, mats, faces = take(api.Geom, ng), take(api.Material, nm), take(api.Face, nf)
-    box = take(api.AABB, 1)[0]
-    assert off == len(blob)
+        return [cls.from_buffer_copy(blob[o + i * sz: o + (i + 1) * sz]) for i in range(n)]
+    geoms = take(api.Geom, off["geoms"], h["ngeoms"])
+    mats = take(api.Material, off["materials"], h["nmaterials"])
+    faces = take(api.Face, off["faces"], h["nfaces"])
+    box = api.AABB()
+    box.lb[:] = h["box"][:3]
+    box.ub[:] = h["box"][3:]
     return geoms, mats, faces, box
+
+
+def scene_bvh(blob: bytes):
+    """-> (nodes[NODE_DTYPE], tris[TRI_DTYPE], faces[synth.FACE_DTYPE], stack_need) views of a packed scene"""
+    from . import synth
+    h, off = scene_sections(blob)
+    nodes = np.frombuffer(blob, NODE_DTYPE, h["nnodes"], off["nodes"])
+    tris = np.frombuffer(blob, TRI_DTYPE, h["nfaces"], off["tris"])
+    faces = np.frombuffer(blob, synth.FACE_DTYPE, h["nfaces"], off["faces"])
+    return nodes, tris, faces, h["stack_need"]
 
 
 def broadcast_bytes(payload, src: int, device):

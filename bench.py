@@ -84,7 +84,7 @@ def main():
             stone.color[:] = [.75, .7, .6]                      # all-diffuse stone
             mats0 = list(mats0) + [stone]
             fnp, lb, ub = synth.make_atrium_mesh(args.mesh, 565, material=len(mats0) - 1)
-            faces0 = [api.Face.from_buffer_copy(fnp[i].tobytes()) for i in range(len(fnp))]
+            faces0 = fnp
             box0 = api.AABB()
             box0.lb[:] = [float(v) for v in lb]
             box0.ub[:] = [float(v) for v in ub]
@@ -94,11 +94,10 @@ def main():
     scene_blob = adist.broadcast_bytes(scene_blob, 0, dev)
     weight_blob = adist.broadcast_bytes(weight_blob, 0, dev)
     cam_bytes = adist.broadcast_bytes(cam_bytes, 0, dev)
-    geoms, mats, faces, box = adist.unpack_scene(scene_blob)
     cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
     zoom, phi0, theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
 
-    ctx.pathtrace_init(geoms, mats, faces, box if faces else None)
+    ctx.pathtrace_init_packed(scene_blob)        # copies only: the BVH inside the blob was built once, on rank 0
     ctx.load_weights(weight_blob)
     ctx.frame_configure(W, H)
     ctx.denoise_set_impl({"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl])

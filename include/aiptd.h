@@ -145,6 +145,16 @@ int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
 int aipt_scene_upload(aipt_ctx* ctx, const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
                       const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box);
 int aipt_scene_free(aipt_ctx* ctx);                      /* pathtraceFree (pathtrace.cu:131-145) */
+/* The same upload in two steps, for multi-GPU hosts (no reference equivalent: the reference is single-GPU):
+ * aipt_scene_pack (host only, no context, no GPU) validates the scene, builds the mesh BVH ONCE and returns one relocatable
+ * blob -- geoms, materials, faces, BVH nodes, leaf triangle records -- that rank 0 broadcasts (RCCL) and every rank hands to
+ * aipt_scene_upload_packed, which only copies.  aipt_scene_upload == pack + upload_packed + aipt_blob_free.
+ * err (optional) receives the message when aipt_scene_pack fails. */
+int  aipt_scene_pack(const aipt_geom* geoms, int ngeoms, const aipt_material* materials, int nmaterials,
+                     const aipt_face* faces, int nfaces, const aipt_aabb* mesh_box, void** blob_out, size_t* bytes_out,
+                     char* err, size_t errlen);
+void aipt_blob_free(void* blob);
+int  aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes);
 /* pathtraceInit, frame-size part: path-state buffers for width x height pixels (allocated once, not per frame). */
 int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
 /* pathtrace (pathtrace.cu:422-528), one iteration.  iter = 1 starts a new image (the interactive loop always does,
@@ -155,6 +165,17 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
  * (pathtrace.cu:81-94, 295-304, 379-387).  Every in-frame element is written each call; padding is left untouched. */
 int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
                float* d_gbuf, int gbuf_rows, int gbuf_stride);
+/* HIP-event timing of the bounce launches on the stream they are launched on (bench.py's roofline leg): up to max_calls
+ * traces are recorded, every `every`-th one after _begin; _end synchronises and returns the summed ms of bounce b's launch in
+ * sum_ms_per_bounce[b] (b < nbounces) and the number of recorded traces.  aipt_trace_kernel_name: the kernel instantiation
+ * that ran bounce `bounce` of the last trace, as rocprofv3 names it. */
+int aipt_trace_profile_begin(aipt_ctx* ctx, int max_calls, int every);
+int aipt_trace_profile_end(aipt_ctx* ctx, double* sum_ms_per_bounce, int nbounces, int* calls);
+int aipt_trace_kernel_name(aipt_ctx* ctx, int bounce, char* kernel, size_t kernel_len);
+/* BVH-walk statistics accumulated since the last reset, only in a library built with -DAIPT_TRACE_STATS (tools/trace_stats.py;
+ * otherwise AIPT_E_STATE): out16 = {lane node visits, wave node-loop trips, lane triangle tests, wave leaf-loop trips, lane leaf
+ * visits, max node visits of one ray, 0, 0, rays that walked with <= 4, 8, 16, 32, 64, 128, more node visits, 0}. */
+int aipt_debug_trace_stats(aipt_ctx* ctx, unsigned long long* out16, int reset);
 /* live-path counts of the last aipt_trace: n_live[b] = paths entering bounce b, b = 0..depth (synchronous). */
 int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n);
 /* first-hit material ids (-1 = miss) per pixel index of the last AIPT_TRACE_RECORD_MAT0 trace (synchronous). */

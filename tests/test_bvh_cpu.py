@@ -1,0 +1,92 @@
+"""The host-side BVH builder (csrc/bvh.cpp, through aipt_scene_pack) checked on the CPU: the packed blob is deterministic,
+every face sits in exactly one leaf, every decoded 8-bit child box contains the boxes of everything below it, the leaf
+records hold the fp32 edges of their faces, and the traversal-stack bound holds."""
+import numpy as np
+import pytest
+
+from ai_path_tracer_denoiser_amd import api, synth
+from ai_path_tracer_denoiser_amd import dist as adist
+
+EMPTY = -2 ** 31
+
+
+def _pack(faces, lb, ub, nmat=2):
+    mats = [api.Material() for _ in range(nmat)]
+    box = api.AABB()
+    box.lb[:] = [float(v) for v in lb]
+    box.ub[:] = [float(v) for v in ub]
+    return api.scene_pack([], mats, faces, box)
+
+
+def _decode(nd, k):
+    s = [np.uint32((int(nd["exps"]) >> (8 * a) & 0xff) << 23).view(np.float32) for a in range(3)]
+    lo = [np.float32(np.float32((int(nd["qlo"][a]) >> (8 * k)) & 0xff) * s[a] + nd["p"][a]) for a in range(3)]
+    hi = [np.float32(np.float32((int(nd["qhi"][a]) >> (8 * k)) & 0xff) * s[a] + nd["p"][a]) for a in range(3)]
+    return np.array(lo), np.array(hi)
+
+
+@pytest.mark.parametrize("make", ["atrium", "living"])
+def test_packed_bvh_is_valid(make):
+    if make == "atrium":
+        faces, lb, ub = synth.make_atrium_mesh(4096, 565, material=1)
+    else:
+        faces, lb, ub, _ = synth.make_living_room_mesh(4096, 565, first_material=0)
+        faces = faces.copy()
+        faces["materialid"] = 1
+    blob = _pack(faces, lb, ub)
+    assert blob == _pack(faces, lb, ub)                               # deterministic
+    nodes, tris, f2, need = adist.scene_bvh(blob)
+    assert np.array_equal(f2, faces)
+    assert sorted(tris["face"].tolist()) == list(range(len(faces)))   # every face in exactly one leaf slot
+    fv = faces["v"][tris["face"]]
+    assert np.array_equal(tris["v0"], fv[:, 0]) and np.array_equal(tris["e1"], fv[:, 1] - fv[:, 0]) \
+        and np.array_equal(tris["e2"], fv[:, 2] - fv[:, 0])           # the fp32 subtractions of intersect.inl:44-45
+    tlo, thi = fv.min(axis=1), fv.max(axis=1)                         # per leaf slot
+
+    seen = np.zeros(len(faces), bool)
+    max_sp = [0]
+
+    def walk(ni, sp):
+        """returns the (lo, hi) of everything below node ni; checks every child's decoded box on the way"""
+        nd = nodes[ni]
+        nk = int(nd["exps"]) >> 24
+        assert 1 <= nk <= 4
+        lo_all, hi_all = np.full(3, np.inf), np.full(3, -np.inf)
+        for k in range(4):
+            ref = int(nd["ref"][k])
+            dlo, dhi = _decode(nd, k)
+            if k >= nk:
+                assert ref == EMPTY and (dlo > dhi).all()             # empty slot: inverted box
+                continue
+            if ref < 0:
+                v = -ref - 1
+                first, cnt = v >> 3, v & 7
+                assert 1 <= cnt <= 4 and not seen[first:first + cnt].any()
+                seen[first:first + cnt] = True
+                lo, hi = tlo[first:first + cnt].min(axis=0), thi[first:first + cnt].max(axis=0)
+            else:
+                max_sp[0] = max(max_sp[0], sp + nk - 1)
+                lo, hi = walk(ref, sp + nk - 1)
+            assert (dlo <= lo).all() and (dhi >= hi).all(), (ni, k, dlo, lo, dhi, hi)
+            lo_all, hi_all = np.minimum(lo_all, lo), np.maximum(hi_all, hi)
+        return lo_all, hi_all
+    walk(0, 0)
+    assert seen.all()
+    assert max_sp[0] <= need <= 72
+
+
+def test_tiny_and_degenerate_meshes_pack():
+    faces, lb, ub = synth.make_atrium_mesh(2048, 1, material=0)
+    for n in (1, 2, 3, 5):
+        blob = _pack(faces[:n].copy(), lb, ub, nmat=1)
+        nodes, tris, _, need = adist.scene_bvh(blob)
+        assert len(tris) == n and len(nodes) >= 1 and sorted(tris["face"].tolist()) == list(range(n))
+    dup = np.concatenate([faces[:64], faces[:64]])                     # coincident faces: SAH degenerates, median split
+    nodes, tris, _, need = adist.scene_bvh(_pack(dup, lb, ub, nmat=1))
+    assert sorted(tris["face"].tolist()) == list(range(128))
+
+
+def test_pack_rejects_bad_scenes():
+    faces, lb, ub = synth.make_atrium_mesh(2048, 1, material=5)
+    with pytest.raises(api.AiptError):
+        _pack(faces, lb, ub, nmat=2)                                   # face material out of range

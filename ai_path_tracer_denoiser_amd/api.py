@@ -79,6 +79,12 @@ ABI = [
                                   C.c_size_t]),
     ("aipt_blob_free", None, [_P]),
     ("aipt_scene_upload_packed", C.c_int, [_P, _P, C.c_size_t]),
+    ("aipt_trace_configure_batch", C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    ("aipt_trace_batch", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, _P, C.c_int, C.c_int, C.c_size_t]),
+    ("aipt_trace_live_counts_frame", C.c_int, [_P, C.c_int, _P, C.c_int]),
+    ("aipt_frames_configure", C.c_int, [_P, C.c_int]),
+    ("aipt_frames", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    ("aipt_frames_gbuffer", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aipt_trace_profile_begin", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_trace_profile_end", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
     ("aipt_trace_kernel_name", C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
@@ -396,6 +402,38 @@ class Context:
               bn_batch: bool = True, carry: bool = True):
         flags = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
         self._ck(lib().aipt_frame(self._h, C.byref(cam), iter, depth, trace_flags, flags, _P(out3.data_ptr())))
+
+    def trace_configure_batch(self, width: int, height: int, batch: int):
+        self._ck(lib().aipt_trace_configure_batch(self._h, width, height, batch))
+
+    def pathtrace_batch(self, cams, iter: int, depth: int, gbufs, flags: int = TRACE_DEFAULT):
+        """aipt_trace_batch: len(cams) frames into gbufs, a float32 device tensor [nframes, 10, rows, stride]"""
+        assert gbufs.is_cuda and gbufs.is_contiguous() and gbufs.dim() == 4 and gbufs.shape[0] >= len(cams) and gbufs.shape[1] == 10
+        ca = (Camera * len(cams))(*cams)
+        self._ck(lib().aipt_trace_batch(self._h, ca, len(cams), iter, depth, flags, _P(gbufs.data_ptr()), gbufs.shape[2],
+                                        gbufs.shape[3], 10 * gbufs.shape[2] * gbufs.shape[3]))
+
+    def live_counts_frame(self, frame: int, depth: int) -> np.ndarray:
+        out = np.zeros(depth + 1, np.int32)
+        self._ck(lib().aipt_trace_live_counts_frame(self._h, frame, out.ctypes.data, depth + 1))
+        return out
+
+    def frames_configure(self, batch: int):
+        self._ck(lib().aipt_frames_configure(self._h, batch))
+
+    def frames(self, cams, iter: int, depth: int, outs, trace_flags: int = TRACE_DEFAULT, bn_batch: bool = True,
+               carry_first: bool = True, carry: bool = True):
+        """aipt_frames: trace len(cams) consecutive frames with one set of launches, denoise them in order into outs[j]."""
+        ca = (Camera * len(cams))(*cams)
+        ptrs = (_P * len(cams))(*[_P(o.data_ptr()) for o in outs[:len(cams)]])
+        f0 = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry_first else 0)
+        f1 = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
+        self._ck(lib().aipt_frames(self._h, ca, len(cams), iter, depth, trace_flags, f0, f1, ptrs))
+
+    def frames_gbuffer(self, frame: int):
+        p, r, s = _P(), C.c_int(), C.c_int()
+        self._ck(lib().aipt_frames_gbuffer(self._h, frame, C.byref(p), C.byref(r), C.byref(s)))
+        return p.value, r.value, s.value
 
     def frame_prefetch(self, cam: Camera, iter: int, depth: int, trace_flags: int = TRACE_DEFAULT):
         """Trace the NEXT frame on the side stream while the current one is denoised; the next frame() call with the

@@ -80,6 +80,8 @@ void aipt_destroy(aipt_ctx* ctx) {
     aipt::trace_destroy(ctx);
     aipt::denoise_destroy(ctx);
     for (float* g : ctx->d_gbufs) if (g) hipFree(g);
+    if (ctx->d_gbatch) hipFree(ctx->d_gbatch);
+    for (auto& ev : ctx->bev) if (ev) hipEventDestroy(ev);
     for (auto& ev : ctx->ev_denoised) if (ev) hipEventDestroy(ev);
     if (ctx->ev_prefetched) hipEventDestroy(ctx->ev_prefetched);
     if (ctx->ev_traced) hipEventDestroy(ctx->ev_traced);
@@ -171,6 +173,8 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     if (rc) return rc;
     if (ctx->side) AIPT_HIP(ctx, hipStreamSynchronize(ctx->side));
     for (float*& g : ctx->d_gbufs) if (g) { hipFree(g); g = nullptr; }
+    if (ctx->d_gbatch) { hipFree(ctx->d_gbatch); ctx->d_gbatch = nullptr; }
+    ctx->fbatch = 1;
     ctx->d_gbuf = nullptr; ctx->front = 0; ctx->pf.valid = false;
     ctx->denoised_valid[0] = ctx->denoised_valid[1] = false;
     const size_t plane = (size_t)wp * hp;
@@ -219,10 +223,11 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
         ctx->front = ctx->pf.buf;
         AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prefetched, 0));
     } else {                                                   // unpipelined: the front G-buffer stays where it is
-        rc = aipt::trace_on_stream(ctx, ctx->stream, cam, iter, depth, trace_flags, ctx->d_gbufs[ctx->front], ctx->fhp, ctx->fwp);
+        rc = aipt::trace_on_stream(ctx, ctx->stream, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[ctx->front], ctx->fhp, ctx->fwp, 0);
         if (rc) return rc;
     }
     ctx->d_gbuf = ctx->d_gbufs[ctx->front];
+    ctx->last_batch = 1;
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
     // the final normalisation pass writes the cropped [3][h][w] image directly (no padded copy, no crop copies)
     rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw);
@@ -233,6 +238,61 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
         AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
         ctx->frame_timed = true;
     }
+    return AIPT_OK;
+}
+
+// ---- batches of frames: one set of trace launches for n consecutive frames, then n denoiser passes in order
+int aipt_frames_configure(aipt_ctx* ctx, int batch) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbuf) return fail(ctx, AIPT_E_STATE, "aipt_frames_configure: call aipt_frame_configure first");
+    if (batch < 1 || batch > 8) return fail(ctx, AIPT_E_INVALID, "aipt_frames_configure: batch %d (1..8)", batch);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    const int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch);
+    if (rc) return rc;
+    if (ctx->d_gbatch) { hipFree(ctx->d_gbatch); ctx->d_gbatch = nullptr; }
+    const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
+    AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_gbatch, sizeof(float) * frame * batch));
+    AIPT_HIP(ctx, hipMemsetAsync(ctx->d_gbatch, 0, sizeof(float) * frame * batch, ctx->stream));   // padding = miss pixels = 0
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->bev[0]) for (auto& ev : ctx->bev) hipEventCreate(&ev);
+    ctx->fbatch = batch;
+    ctx->pf.valid = false;
+    return AIPT_OK;
+}
+
+int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
+                uint32_t dn_flags_first, uint32_t dn_flags_rest, float* const* d_out3) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbatch) return fail(ctx, AIPT_E_STATE, "aipt_frames: call aipt_frames_configure first");
+    if (!cams || !d_out3 || nframes < 1 || nframes > ctx->fbatch)
+        return fail(ctx, AIPT_E_INVALID, "aipt_frames: %d frames, configured for %d", nframes, ctx->fbatch);
+    for (int j = 0; j < nframes; j++) if (!d_out3[j]) return fail(ctx, AIPT_E_INVALID, "aipt_frames: output %d is NULL", j);
+    ctx->pf.valid = false;
+    const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
+    if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[0], ctx->stream));
+    int rc = aipt::trace_on_stream(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatch, ctx->fhp, ctx->fwp, frame);
+    if (rc) return rc;
+    if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
+    for (int j = 0; j < nframes; j++) {
+        rc = aipt::denoise_run(ctx, ctx->d_gbatch + j * frame, d_out3[j], j == 0 ? dn_flags_first : dn_flags_rest, ctx->fh, ctx->fw);
+        if (rc) return rc;
+    }
+    ctx->d_gbuf = ctx->d_gbatch + (size_t)(nframes - 1) * frame;
+    ctx->last_batch = nframes;
+    if (ctx->frame_timing) {
+        AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
+        ctx->frame_timed = true;
+    }
+    return AIPT_OK;
+}
+
+int aipt_frames_gbuffer(aipt_ctx* ctx, int frame, float** d_gbuf, int* rows, int* stride) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbatch || frame < 0 || frame >= ctx->fbatch) return fail(ctx, AIPT_E_STATE, "aipt_frames_gbuffer: frame %d of %d", frame, ctx->fbatch);
+    if (d_gbuf) *d_gbuf = ctx->d_gbatch + (size_t)frame * 10 * ctx->fwp * ctx->fhp;
+    if (rows) *rows = ctx->fhp;
+    if (stride) *stride = ctx->fwp;
     return AIPT_OK;
 }
 
@@ -251,7 +311,7 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     const int back = ctx->front ^ 1;
     // the denoise that last read the back G-buffer must be done before the trace overwrites it
     if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_denoised[back], 0));
-    const int rc = aipt::trace_on_stream(ctx, ctx->side, cam, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp);
+    const int rc = aipt::trace_on_stream(ctx, ctx->side, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
     if (rc) return rc;
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
     ctx->pf.valid = true; ctx->pf.cam = *cam; ctx->pf.iter = iter; ctx->pf.depth = depth; ctx->pf.flags = trace_flags;
@@ -266,8 +326,9 @@ int aipt_frame_last_times(aipt_ctx* ctx, float* trace_ms, float* denoise_ms) {
     float a = 0, b = 0;
     AIPT_HIP(ctx, hipEventElapsedTime(&a, ctx->fev[0], ctx->fev[1]));
     AIPT_HIP(ctx, hipEventElapsedTime(&b, ctx->fev[1], ctx->fev[2]));
-    if (trace_ms) *trace_ms = a;
-    if (denoise_ms) *denoise_ms = b;
+    // after aipt_frames: per-frame averages over the batch
+    if (trace_ms) *trace_ms = a / (float)ctx->last_batch;
+    if (denoise_ms) *denoise_ms = b / (float)ctx->last_batch;
     return AIPT_OK;
 }
 

@@ -42,6 +42,11 @@ struct aipt_ctx {
     hipStream_t last_trace_stream = nullptr;
     bool denoised_valid[2] = {false, false};
     struct { bool valid = false; aipt_camera cam; int iter = 0, depth = 0; uint32_t flags = 0; int buf = 0; } pf;
+    // aipt_frames: a batch of frames traced together, then denoised in order
+    int fbatch = 1;
+    float* d_gbatch = nullptr;    // [fbatch][10][fhp][fwp]
+    hipEvent_t bev[2] = {nullptr, nullptr};
+    int last_batch = 1;
 };
 
 namespace aipt {
@@ -81,8 +86,9 @@ static_assert(sizeof(TriRec) == 48, "TriRec");
 int build_bvh4(const aipt_face* faces, int nfaces, std::vector<Bvh4Node>& nodes, std::vector<int>& leaf_faces);
 
 // aipt_trace on an explicit stream; orders itself after the previous trace when that ran on another stream
-int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags, float* d_gbuf,
-                    int gbuf_rows, int gbuf_stride);
+// (nframes > 1: a batch of frames traced by one set of launches, G-buffer f at d_gbuf + f * gbuf_frame floats)
+int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int nframes, int iter, int depth, uint32_t flags,
+                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame);
 // wait for the main stream and, if one exists, the prefetch stream
 inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);

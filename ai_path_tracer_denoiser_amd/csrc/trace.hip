@@ -45,6 +45,7 @@ struct alignas(16) DevFaceP { DevFace f; int pad; };   // 80 bytes: five 16-byte
 static_assert(sizeof(DevFaceP) == 80, "DevFaceP");
 
 constexpr int MAX_DEPTH = 64;
+constexpr int BMAX = 8;        // most frames one batched trace (aipt_trace_batch) can hold
 
 struct TraceState {
     DevGeom* d_geoms = nullptr; int ngeoms = 0;
@@ -57,6 +58,10 @@ struct TraceState {
     aipt_aabb box{};
     bool have_scene = false;
     int W = 0, H = 0, P = 0, nblk = 0;
+    int batch = 1;                // frames the per-path buffers below can hold (aipt_trace_configure_batch): sized batch * P
+    aipt_camera* d_cams = nullptr;   // [BMAX] cameras of a batched trace
+    int* d_nlive_f = nullptr;     // [MAX_DEPTH+1][BMAX] live paths per bounce and frame
+    int last_frames = 1;
     float4* d_state = nullptr;    // [3][P]: (ox oy oz dx) (dy dz cr cg) (cb rem . .)
     int* d_cnt = nullptr;         // per-workgroup live counts of the last bounce
     int* d_alive = nullptr;       // [P] per array slot: does the path survive the bounce?
@@ -80,7 +85,14 @@ struct TraceState {
 };
 
 struct TraceParams {
-    aipt_camera cam;
+    aipt_camera cam;             // the camera of a single-frame trace (kernel argument); batched: cams[frame] in HBM
+    const aipt_camera* cams;
+    int nframes;                 // frames traced together: path i = frame i / P, pixel i % P
+    int PT;                      // nframes * P paths
+    size_t PS;                   // plane stride of the per-path buffers (their capacity, batch * P)
+    size_t gbuf_frame;           // floats between the G-buffers of consecutive frames
+    int* n_live_f;               // [MAX_DEPTH+1][BMAX] live paths per bounce and frame (batched: the RNG index is the rank
+                                 // among the live paths of the SAME frame, as an unbatched trace of that frame computes it)
     int iter, trace_depth, bounce;
     uint32_t flags;
     int W, H, P;
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = p.P;
-    float4* S0 = p.st; float4* S1 = p.st + (size_t)P; float4* S2 = p.st + (size_t)2 * P;
+    float4* S0 = p.st; float4* S1 = p.st + p.PS; float4* S2 = p.st + 2 * p.PS;
 
     // ---- which path does this thread advance, and at which index would thrust::partition have left it?
     // Bounce 0: thread t = pixel t.  Later bounces walk the LIVE LIST written by trace_compact: entry t is the pixel of the
@@ -561,7 +573,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     bool alive;
     const int t = blockIdx.x * 256 + tid;
     if (FIRST) {
-        i = t; idx = t; alive = t < P; rem = p.trace_depth;
+        i = t; idx = t; alive = t < p.PT; rem = p.trace_depth;
     } else {
         const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
         if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
@@ -571,6 +583,18 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         alive = t < n;
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
+    }
+    // batched trace: frame and pixel of the path; the RNG index counts inside the frame
+    int fr = 0, pix = i;
+    if (p.nframes > 1) {
+        fr = i / P;
+        pix = i - fr * P;
+        if (FIRST || !(p.flags & AIPT_TRACE_COMPACT)) idx = pix;
+        else {
+            int foff = 0;
+            for (int k = 0; k < p.nframes - 1; k++) foff += k < fr ? p.n_live_f[p.bounce * BMAX + k] : 0;
+            idx = t - foff;
+        }
     }
 
     // primitives and materials into LDS: the candidate loop and the shader index them per lane
@@ -590,23 +614,25 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     if (alive) {
         v3 o, d, col;
         if (FIRST) {                                                             // generateRayFromCamera :155-182
-            const int x = i % p.W, y = i / p.W;
-            const v3 view = V(p.cam.view[0], p.cam.view[1], p.cam.view[2]);
-            const v3 right = V(p.cam.right[0], p.cam.right[1], p.cam.right[2]);
-            const v3 up = V(p.cam.up[0], p.cam.up[1], p.cam.up[2]);
-            o = V(p.cam.position[0], p.cam.position[1], p.cam.position[2]);
+            const int x = pix % p.W, y = pix / p.W;
+            aipt_camera cam = p.cam;
+            if (p.nframes > 1) cam = p.cams[fr];
+            const v3 view = V(cam.view[0], cam.view[1], cam.view[2]);
+            const v3 right = V(cam.right[0], cam.right[1], cam.right[2]);
+            const v3 up = V(cam.up[0], cam.up[1], cam.up[2]);
+            o = V(cam.position[0], cam.position[1], cam.position[2]);
             col = V(1.0f, 1.0f, 1.0f);
             float jx = 0.0f, jy = 0.0f;
             if (p.flags & AIPT_TRACE_AA) {
-                uint32_t rng = make_seed(p.iter, i, 0);      // uninitialised in the reference, defined as 0
+                uint32_t rng = make_seed(p.iter, pix, 0);    // uninitialised in the reference, defined as 0
                 jx = u01(rng, -0.5f, 0.5f);
                 jy = u01(rng, -0.5f, 0.5f);
             }
-            float sx = (float)x - (float)p.cam.resolution[0] * 0.5f;
-            float sy = (float)y - (float)p.cam.resolution[1] * 0.5f;
+            float sx = (float)x - (float)cam.resolution[0] * 0.5f;
+            float sy = (float)y - (float)cam.resolution[1] * 0.5f;
             if (p.flags & AIPT_TRACE_AA) { sx = sx + jx; sy = sy + jy; }
-            d = vnormalize(vsub(vsub(view, vscale(vscale(right, p.cam.pixelLength[0]), sx)),
-                                vscale(vscale(up, p.cam.pixelLength[1]), sy)));
+            d = vnormalize(vsub(vsub(view, vscale(vscale(right, cam.pixelLength[0]), sx)),
+                                vscale(vscale(up, cam.pixelLength[1]), sy)));
         } else {
             const float4 a = S0[i], b = S1[i], c = S2[i];
             o = V(a.x, a.y, a.z);
@@ -663,7 +689,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 }
             } else {
                 int best_slot = -1;
-                WalkStack st{s_stack + tid, p.stack_ovf + t, (size_t)p.P, 0};
+                WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0};
                 bvh4_nearest(p, o, d, st, t_min, best_slot);
                 if (best_slot >= 0) {
                     // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
@@ -689,8 +715,8 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
         if (p.sortkey) p.sortkey[t] = hit ? materialid : 0;        // the hit record's materialId (memset 0, :478)
         const v3 surfN = vnormalize(normal);
-        const int x = i % p.W, y = i / p.W;
-        const size_t gd = (size_t)y * p.stride + (size_t)(p.W - x - 1);         // h-flipped destination (:297-299)
+        const int x = pix % p.W, y = pix / p.W;
+        const size_t gd = (size_t)fr * p.gbuf_frame + (size_t)y * p.stride + (size_t)(p.W - x - 1);   // h-flipped destination (:297-299)
 
         // ---- shadeMaterial :333-390
         int new_rem;
@@ -725,7 +751,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             // starts from zero (pathtraceInit memsets it, :102), so it is just this path's colour.
             const float fiter = (float)p.iter;
             float* gb = p.gbuf + gd;
-            const size_t ii = (size_t)y * p.W + (size_t)(p.W - x - 1);
+            const size_t ii = (size_t)fr * 3 * P + (size_t)y * p.W + (size_t)(p.W - x - 1);
             float ax = col.x, ay = col.y, az = col.z;
             if (p.iter > 1) { ax = p.image[ii] + col.x; ay = p.image[ii + P] + col.y; az = p.image[ii + 2 * (size_t)P] + col.z; }
             p.image[ii] = ax; p.image[ii + P] = ay; p.image[ii + 2 * (size_t)P] = az;
@@ -750,6 +776,16 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         p.cnt[blockIdx.x] = c;
         if (c) atomicAdd(&p.n_live[p.bounce + 1], c);
     }
+    if (p.nframes > 1) {                            // survivors per frame (a wave can straddle frames)
+        unsigned long long left = m2;
+        while (left) {
+            const int l = __ffsll((long long)left) - 1;
+            const int ff = __shfl(fr, l);
+            const unsigned long long same = __ballot(alive_after && fr == ff);
+            if (lane == l) atomicAdd(&p.n_live_f[(p.bounce + 1) * BMAX + ff], __popcll(same));
+            left &= ~same;
+        }
+    }
 }
 
 // Stable stream compaction of the live list (the wave64 ballot/popcount analogue of thrust::partition, pathtrace.cu:505):
@@ -759,7 +795,7 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     __shared__ int s_wave[4];
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = p.bounce == 0 ? p.P : p.n_live[p.bounce];
+    const int n = p.bounce == 0 ? p.PT : p.n_live[p.bounce];
     if ((int)(blockIdx.x * 256) >= n) return;
     const int t = blockIdx.x * 256 + tid;
     int i = 0;
@@ -851,6 +887,8 @@ static void free_frame(TraceState* s) {
     hipFree(s->d_state); hipFree(s->d_cnt); hipFree(s->d_alive); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
     for (int*& l : s->d_live) { hipFree(l); l = nullptr; }
     hipFree(s->d_cache); hipFree(s->d_sortkey); hipFree(s->d_hist); hipFree(s->d_stack_ovf);
+    hipFree(s->d_cams); hipFree(s->d_nlive_f);
+    s->d_cams = nullptr; s->d_nlive_f = nullptr;
     s->d_stack_ovf = nullptr; s->ovf_entries = 0;
     s->d_state = nullptr; s->d_cnt = nullptr; s->d_alive = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
     s->d_cache = nullptr; s->d_sortkey = nullptr; s->d_hist = nullptr; s->hist_keys = 0; s->cache_valid = false;
@@ -1071,46 +1109,65 @@ int aipt_scene_free(aipt_ctx* ctx) {
     return AIPT_OK;
 }
 
-int aipt_trace_configure(aipt_ctx* ctx, int width, int height) {
+int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) {
     AIPT_CHECK_CTX(ctx);
-    if (width <= 0 || height <= 0 || (long)width * height > (1l << 30))
-        return fail(ctx, AIPT_E_INVALID, "aipt_trace_configure: %dx%d", width, height);
+    if (width <= 0 || height <= 0 || batch < 1 || batch > BMAX || (long)width * height * batch > (1l << 30))
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace_configure: %dx%d x %d frames (1..%d)", width, height, batch, BMAX);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
-    if (s->W == width && s->H == height && s->d_state) return AIPT_OK;
+    if (s->W == width && s->H == height && s->batch == batch && s->d_state) return AIPT_OK;
     free_frame(s);
-    const int P = width * height, nblk = (P + 255) / 256;
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float4) * 3 * (size_t)P));
+    const int P = width * height;
+    const size_t PT = (size_t)P * batch;
+    const int nblk = (int)((PT + 255) / 256);
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float4) * 3 * PT));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt, sizeof(int) * nblk));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_alive, sizeof(int) * (size_t)P));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_alive, sizeof(int) * PT));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * (size_t)P));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * (size_t)P));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[0], sizeof(int) * (size_t)P));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[1], sizeof(int) * (size_t)P));
-    s->W = width; s->H = height; s->P = P; s->nblk = nblk;
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive_f, sizeof(int) * (MAX_DEPTH + 1) * BMAX));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cams, sizeof(aipt_camera) * BMAX));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * PT));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * PT));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[0], sizeof(int) * PT));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[1], sizeof(int) * PT));
+    s->W = width; s->H = height; s->P = P; s->nblk = nblk; s->batch = batch;
     s->mat0_valid = false; s->cache_valid = false;
     return AIPT_OK;
+}
+
+int aipt_trace_configure(aipt_ctx* ctx, int width, int height) { return aipt_trace_configure_batch(ctx, width, height, 1); }
+
+int aipt_trace_batch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t flags,
+                     float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame_floats) {
+    AIPT_CHECK_CTX(ctx);
+    return aipt::trace_on_stream(ctx, ctx->stream, cams, nframes, iter, depth, flags, d_gbuf, gbuf_rows, gbuf_stride, gbuf_frame_floats);
 }
 
 int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
                float* d_gbuf, int gbuf_rows, int gbuf_stride) {
     AIPT_CHECK_CTX(ctx);
-    return aipt::trace_on_stream(ctx, ctx->stream, cam, iter, depth, flags, d_gbuf, gbuf_rows, gbuf_stride);
+    return aipt::trace_on_stream(ctx, ctx->stream, cam, 1, iter, depth, flags, d_gbuf, gbuf_rows, gbuf_stride, 0);
 }
 
 extern "C++" {
 namespace aipt {
-int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int iter, int depth, uint32_t flags,
-                    float* d_gbuf, int gbuf_rows, int gbuf_stride) {
+int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int nframes, int iter, int depth, uint32_t flags,
+                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame) {
     TraceState* s = tstate(ctx);
     if (!s->have_scene) return fail(ctx, AIPT_E_STATE, "aipt_trace: no scene uploaded");
     if (!s->d_state) return fail(ctx, AIPT_E_STATE, "aipt_trace: call aipt_trace_configure first");
     if (!cam || !d_gbuf) return fail(ctx, AIPT_E_INVALID, "aipt_trace: NULL argument");
-    if (cam->resolution[0] != s->W || cam->resolution[1] != s->H)
-        return fail(ctx, AIPT_E_INVALID, "aipt_trace: camera is %dx%d, configured %dx%d", cam->resolution[0],
-                    cam->resolution[1], s->W, s->H);
+    if (nframes < 1 || nframes > s->batch)
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace: %d frames, configured for %d (aipt_trace_configure_batch)", nframes, s->batch);
+    for (int f = 0; f < nframes; f++)
+        if (cam[f].resolution[0] != s->W || cam[f].resolution[1] != s->H)
+            return fail(ctx, AIPT_E_INVALID, "aipt_trace: camera is %dx%d, configured %dx%d", cam[f].resolution[0],
+                        cam[f].resolution[1], s->W, s->H);
+    if (nframes > 1 && (iter != 1 || (flags & (AIPT_TRACE_SORT_MATERIAL | AIPT_TRACE_CACHE_FIRST_BOUNCE | AIPT_TRACE_MOTION_BLUR))))
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace_batch: a batch holds iteration-1 frames without the sort / cache / motion-blur toggles");
+    if (nframes > 1 && gbuf_frame < (size_t)10 * gbuf_rows * gbuf_stride)
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace_batch: G-buffers of consecutive frames overlap");
     if (depth < 1 || depth > MAX_DEPTH) return fail(ctx, AIPT_E_INVALID, "aipt_trace: depth %d not in 1..%d", depth, MAX_DEPTH);
     if (iter < 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace: iter %d (iterations count from 1, main.cpp:149)", iter);
     if (gbuf_rows < s->H || gbuf_stride < s->W) return fail(ctx, AIPT_E_INVALID, "aipt_trace: G-buffer %dx%d too small", gbuf_rows, gbuf_stride);
@@ -1121,12 +1178,13 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     if (sortmat && s->nmats > 256) return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_SORT_MATERIAL supports up to 256 materials (%d)", s->nmats);
     if (cache && ((flags & AIPT_TRACE_AA) || blur))             // the reference's asserts, pathtrace.cu:435-436
         return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE is only legal without AIPT_TRACE_AA and AIPT_TRACE_MOTION_BLUR");
+    if (cache && s->batch > 1) return fail(ctx, AIPT_E_INVALID, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE needs a single-frame configuration");
     if (cache && !s->d_cache) AIPT_HIP(ctx, hipMalloc((void**)&s->d_cache, sizeof(float) * 8 * (size_t)s->P));
     if (cache && iter > 1 && !s->cache_valid)
         return fail(ctx, AIPT_E_STATE, "aipt_trace: AIPT_TRACE_CACHE_FIRST_BOUNCE at iter %d without a cached iter 1", iter);
     if (sortmat) {
-        if (!s->d_live[2]) AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[2], sizeof(int) * (size_t)s->P));
-        if (!s->d_sortkey) AIPT_HIP(ctx, hipMalloc((void**)&s->d_sortkey, sizeof(int) * (size_t)s->P));
+        if (!s->d_live[2]) AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[2], sizeof(int) * (size_t)s->P * s->batch));
+        if (!s->d_sortkey) AIPT_HIP(ctx, hipMalloc((void**)&s->d_sortkey, sizeof(int) * (size_t)s->P * s->batch));
         if (s->hist_keys < s->nmats) {
             AIPT_HIP(ctx, hipStreamSynchronize(st));
             hipFree(s->d_hist); s->d_hist = nullptr;
@@ -1138,7 +1196,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     if (ovf_need > s->ovf_entries) {
         AIPT_HIP(ctx, hipStreamSynchronize(st));
         hipFree(s->d_stack_ovf); s->d_stack_ovf = nullptr; s->ovf_entries = 0;
-        AIPT_HIP(ctx, hipMalloc((void**)&s->d_stack_ovf, sizeof(int) * (size_t)ovf_need * s->P));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_stack_ovf, sizeof(int) * (size_t)ovf_need * s->P * s->batch));
         s->ovf_entries = ovf_need;
     }
     if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
@@ -1158,8 +1216,15 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
         }
     }
     TraceParams p;
-    p.cam = *cam; p.iter = iter; p.trace_depth = depth; p.flags = flags;
+    p.cam = cam[0]; p.iter = iter; p.trace_depth = depth; p.flags = flags;
     p.W = s->W; p.H = s->H; p.P = s->P;
+    p.nframes = nframes; p.PT = nframes * s->P; p.PS = (size_t)s->P * s->batch; p.gbuf_frame = gbuf_frame;
+    p.cams = s->d_cams; p.n_live_f = s->d_nlive_f;
+    const int nblk = (p.PT + 255) / 256;
+    if (nframes > 1) {
+        AIPT_HIP(ctx, hipMemcpyAsync(s->d_cams, cam, sizeof(aipt_camera) * nframes, hipMemcpyHostToDevice, st));
+        AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive_f, 0, sizeof(int) * (MAX_DEPTH + 1) * BMAX, st));
+    }
     p.st = s->d_state;
     p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats; p.nmats = s->nmats;
     p.faces = s->d_faces; p.nfaces = s->nfaces; p.box = s->box;
@@ -1171,7 +1236,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     p.image = s->d_image;
     p.cache = s->d_cache; p.cache_mode = cache ? (iter == 1 ? 1 : 2) : 0;
     p.sortkey = sortmat ? s->d_sortkey : nullptr;
-    p.hist = s->d_hist; p.nkeys = s->nmats; p.nblk = s->nblk;
+    p.hist = s->d_hist; p.nkeys = s->nmats; p.nblk = nblk;
     p.sort_in = nullptr; p.sort_out = nullptr;
     p.stack_ovf = s->d_stack_ovf;
     const bool prof = s->prof_max && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
@@ -1189,20 +1254,20 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
         p.live_out = s->d_live[nxt];
         hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
-        if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
-        else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(s->nblk), dim3(256), lds_scene, st, p);
-        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(s->nblk), dim3(256), stack_bytes, st, p);
-        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(s->nblk), dim3(256), lds_scene, st, p);
+        if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
+        else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
+        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
+        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[1], st));
         if (b + 1 < depth) {
-            hipLaunchKernelGGL(trace_compact, dim3(s->nblk), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(trace_compact, dim3(nblk), dim3(256), 0, st, p);
             cur = nxt;
             if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)
                 const int srt = (cur + 1) % 3;
                 p.sort_in = s->d_live[cur]; p.sort_out = s->d_live[srt];
-                hipLaunchKernelGGL(trace_sort_hist, dim3(s->nblk), dim3(256), 0, st, p);
+                hipLaunchKernelGGL(trace_sort_hist, dim3(nblk), dim3(256), 0, st, p);
                 hipLaunchKernelGGL(trace_sort_scan, dim3(1), dim3(1024), 0, st, p);
-                hipLaunchKernelGGL(trace_sort_scatter, dim3(s->nblk), dim3(256), 0, st, p);
+                hipLaunchKernelGGL(trace_sort_scatter, dim3(nblk), dim3(256), 0, st, p);
                 cur = srt;
             }
         }
@@ -1216,6 +1281,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int i
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
     ctx->last_trace_stream = st;
     s->last_depth = depth;
+    s->last_frames = nframes;
     s->mat0_valid = p.mat0 != nullptr;
     return AIPT_OK;
 }
@@ -1285,8 +1351,22 @@ int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n) {
     if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
     AIPT_HIP(ctx, hipMemcpyAsync(tmp.data(), s->d_nlive, sizeof(int) * (MAX_DEPTH + 1), hipMemcpyDeviceToHost, ctx->stream));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
-    tmp[0] = s->P;
+    tmp[0] = s->P * s->last_frames;
     for (int i = 0; i < n; i++) h_n_live[i] = i <= s->last_depth ? tmp[i] : 0;
+    return AIPT_OK;
+}
+
+int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n) {
+    AIPT_CHECK_CTX(ctx);
+    TraceState* s = tstate(ctx);
+    if (!s->d_nlive || !s->last_depth) return fail(ctx, AIPT_E_STATE, "aipt_trace_live_counts_frame: no trace has run");
+    if (!h_n_live || n < 1 || frame < 0 || frame >= s->last_frames) return fail(ctx, AIPT_E_INVALID, "aipt_trace_live_counts_frame: bad arguments");
+    if (s->last_frames == 1) return aipt_trace_live_counts(ctx, h_n_live, n);
+    std::vector<int> tmp((MAX_DEPTH + 1) * BMAX);
+    if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
+    AIPT_HIP(ctx, hipMemcpyAsync(tmp.data(), s->d_nlive_f, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, ctx->stream));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    for (int i = 0; i < n; i++) h_n_live[i] = i == 0 ? s->P : (i <= s->last_depth ? tmp[i * BMAX + frame] : 0);
     return AIPT_OK;
 }
 
@@ -1294,7 +1374,7 @@ int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n) {
     AIPT_CHECK_CTX(ctx);
     TraceState* s = tstate(ctx);
     if (!s->mat0_valid) return fail(ctx, AIPT_E_STATE, "aipt_trace_first_hit_materials: last trace did not record them");
-    if (!h_mat || n != s->P) return fail(ctx, AIPT_E_INVALID, "aipt_trace_first_hit_materials: n=%d, expected %d", n, s->P);
+    if (!h_mat || n != s->P * s->last_frames) return fail(ctx, AIPT_E_INVALID, "aipt_trace_first_hit_materials: n=%d, expected %d", n, s->P * s->last_frames);
     if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
     AIPT_HIP(ctx, hipMemcpyAsync(h_mat, s->d_mat0, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));

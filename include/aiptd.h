@@ -165,6 +165,15 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
  * (pathtrace.cu:81-94, 295-304, 379-387).  Every in-frame element is written each call; padding is left untouched. */
 int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
                float* d_gbuf, int gbuf_rows, int gbuf_stride);
+/* Batched trace (no reference equivalent; the frame sequence is the data-parallel axis): nframes <= batch
+ * iteration-1 frames with their own cameras are traced by ONE set of bounce launches -- a single 1280x720 frame leaves most of
+ * the chip idle in the later bounces.  Frame f writes the G-buffer at d_gbuf + f * gbuf_frame_floats.  Every frame's
+ * result is bit-identical to its own aipt_trace (the RNG index of a path is its rank among the live paths of ITS frame).  The
+ * sort / cache / motion-blur toggles and iter > 1 are single-frame only.  aipt_trace_configure == batch 1. */
+int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch);
+int aipt_trace_batch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t flags,
+                     float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame_floats);
+int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n);   /* of one frame of the last batch */
 /* HIP-event timing of the bounce launches on the stream they are launched on (bench.py's roofline leg): up to max_calls
  * traces are recorded, every `every`-th one after _begin; _end synchronises and returns the summed ms of bounce b's launch in
  * sum_ms_per_bounce[b] (b < nbounces) and the number of recorded traces.  aipt_trace_kernel_name: the kernel instantiation
@@ -232,6 +241,14 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
  * frames.  Only iter == 1 frames can be prefetched (planes 3-9 of later iterations live in the buffer iteration 1 wrote):
  * other values return AIPT_E_INVALID.  aipt_sync waits for both streams. */
 int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
+/* Frame batches: aipt_frames_configure(batch <= 8) after aipt_frame_configure; aipt_frames traces nframes consecutive frames
+ * with one set of launches (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the others with
+ * dn_flags_rest (e.g. carry the hidden state inside the batch) -- into d_out3[0..nframes).  Same results as nframes calls of
+ * aipt_frame.  aipt_frame_last_times then reports per-frame averages over the batch. */
+int aipt_frames_configure(aipt_ctx* ctx, int batch);
+int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
+                uint32_t dn_flags_first, uint32_t dn_flags_rest, float* const* d_out3);
+int aipt_frames_gbuffer(aipt_ctx* ctx, int frame, float** d_gbuf, int* rows, int* stride);
 /* the context-owned padded G-buffer float[10][Hp][Wp] of the last aipt_frame (device pointer) and its padded size */
 int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
 /* per-stage GPU time of the last aipt_frame with timing enabled (ms; synchronous) */

@@ -127,6 +127,7 @@ assert (C.sizeof(Geom), C.sizeof(Face), C.sizeof(Material), C.sizeof(Camera), C.
 
 SPHERE, CUBE = 0, 1
 TRACE_AA, TRACE_COMPACT, TRACE_SORT_MATERIAL, TRACE_CACHE_FIRST_BOUNCE = 1, 2, 32, 64     # = include/aiptd.h AIPT_TRACE_*
+TRACE_ORACLE_BVH = 256       # oracle only: the face loop through a CPU BVH (oracle/trace_bvh.c), same result
 
 
 def _trace_lib():

@@ -393,6 +393,12 @@ static void generateRay(const orc_camera* cam, int iter, int traceDepth, int x, 
     seg->remainingBounces = traceDepth;
 }
 
+/* trace_bvh.c: the same nearest face as the loop below, through a CPU BVH (flag 256 of orc_pathtrace_ex) */
+void orc_bvh_prepare(const orc_face* faces, int nfaces);
+void orc_bvh_nearest(const orc_face* faces, int nfaces, const float* ro, const float* rd, float* t_min, int* best,
+                     float* P, float* N);
+static int g_use_bvh = 0;
+
 static void computeIntersection(const path_t* ps, const orc_geom* geoms, int ngeoms, const orc_face* faces, int nfaces,
                                 const orc_aabb* box, hit_t* out, v3* raw_normal) {   /* :200-306 */
     float t_min = FLT_MAX;
@@ -411,7 +417,15 @@ static void computeIntersection(const path_t* ps, const orc_geom* geoms, int nge
             ip = V(P[0], P[1], P[2]); normal = V(N[0], N[1], N[2]);
         }
     }
-    if (nfaces && orc_ray_aabb(ro, rd, box)) {      /* RAY_CULLING true (:23, :258) */
+    int walked = 0;
+    if (g_use_bvh && nfaces && orc_ray_aabb(ro, rd, box)) {
+        int best = -1;
+        float tm = t_min;
+        orc_bvh_nearest(faces, nfaces, ro, rd, &tm, &best, P, N);
+        if (best >= 0) { t_min = tm; materialid = faces[best].materialid; ip = V(P[0], P[1], P[2]); normal = V(N[0], N[1], N[2]); }
+        walked = best != -2;                        /* -2: tree not prepared for this array -> the exhaustive loop */
+    }
+    if (!walked && nfaces && orc_ray_aabb(ro, rd, box)) {      /* RAY_CULLING true (:23, :258) */
         for (int i = 0; i < nfaces; i++) {
             const float t = orc_triangle_test(&faces[i], ro, rd, P, N);
             if (t > 0.0f && t_min > t) {
@@ -486,6 +500,8 @@ int orc_pathtrace_accum(const orc_camera* cam, const orc_geom* geoms, int ngeoms
  *                         sort_by_key -> stable_sort_by_key; rocThrust likewise), so the result is deterministic: a stable
  *                         sort of the surviving paths by those keys.  The next bounce seeds each path's RNG with its
  *                         slot after the sort (:351).
+ * 256  (oracle only)      walk a CPU BVH instead of looping over all faces: same result (trace_bvh.c), so that full-size
+ *                         frames can be checked and timed
  *  64  CACHE_BOUNCE       iter == 1: the bounce-0 hit records are saved (:466-472); iter > 1: bounce 0 reuses them instead of
  *                         intersecting (:473-476).  Only legal with AA off (assert :435).  cache = caller-held P * 36 bytes.
  */
@@ -504,6 +520,8 @@ int orc_pathtrace_ex(const orc_camera* cam, const orc_geom* geoms, int ngeoms, c
     const size_t plane = (size_t)W * Hp;
     const int aa = (flags & 1u) != 0, compact = (flags & 2u) != 0, sortmat = (flags & 32u) != 0;
     const int use_cache = (flags & 64u) != 0 && cache != NULL;
+    g_use_bvh = (flags & 256u) != 0;                /* test-side acceleration of the face loop, same result (trace_bvh.c) */
+    if (g_use_bvh) orc_bvh_prepare(faces, nfaces);
     path_t* paths = (path_t*)malloc(sizeof(path_t) * P);
     path_t* tmp = (path_t*)malloc(sizeof(path_t) * P);
     hit_t* hits = (hit_t*)malloc(sizeof(hit_t) * P);

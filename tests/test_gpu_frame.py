@@ -113,3 +113,93 @@ def test_frame_sharding_is_equivalent_to_one_rank_with_resets():
         ctx.sync()
         assert np.array_equal(out.cpu().numpy(), sharded[g]), f"frame {g}"
     ctx.close()
+
+
+def _mesh_scene(res, depth, ntri=4096):
+    """Cornell + reflective atrium as api structs (parsed by the product's front end)"""
+    sc = api.Scene(CORNELL, res=res, depth=depth)
+    mats = list(sc.materials) + [api.Material.from_buffer_copy(synth.STONE), api.Material.from_buffer_copy(synth.MIRROR)]
+    first = len(sc.materials)
+    faces, lb, ub = synth.make_atrium_mesh(ntri, 565, material=first, floor_material=first + 1, column_material=first + 1)
+    box = api.AABB()
+    box.lb[:] = [float(v) for v in lb]
+    box.ub[:] = [float(v) for v in ub]
+    return sc, mats, faces, box
+
+
+def test_batched_trace_equals_single_frame_traces():
+    """aipt_trace_batch: frames traced by one set of launches are bit-identical to their own aipt_trace -- G-buffer, live counts
+    per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame)."""
+    import torch
+    W, H, depth = 100, 60, 6               # 6000 pixels per frame: the frames straddle workgroups and waves
+    sc, mats, faces, box = _mesh_scene((W, H), depth)
+    cams = [sc.orbit(phi=sc.phi + 0.15 * k) for k in range(5)]
+    fl = api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0
+    ctx = api.Context(0)
+    ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
+    singles = []
+    g1 = torch.zeros(10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    for c in cams:
+        ctx.pathtrace(c, 1, depth, g1, fl)
+        ctx.sync()
+        singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy(), ctx.first_hit_materials(W * H).copy()))
+    ctx.trace_configure_batch(W, H, 5)
+    gb = torch.zeros(5, 10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    for nf in (5, 3, 1):
+        gb.zero_()
+        torch.cuda.synchronize()
+        ctx.pathtrace_batch(cams[:nf], 1, depth, gb, fl)
+        ctx.sync()
+        got = gb.cpu().numpy()
+        mats0 = ctx.first_hit_materials(W * H * nf).reshape(nf, -1)
+        for f in range(nf):
+            g_ref, n_ref, m_ref = singles[f]
+            assert np.array_equal(got[f].view(np.uint32), g_ref.view(np.uint32)), (nf, f)
+            assert ctx.live_counts_frame(f, depth).tolist() == n_ref.tolist(), (nf, f)
+            assert np.array_equal(mats0[f], m_ref)
+        assert ctx.live_counts(depth).tolist() == np.sum([singles[f][1] for f in range(nf)], axis=0).tolist()
+    with pytest.raises(api.AiptError):
+        ctx.pathtrace_batch(cams[:2], 2, depth, gb, fl)                     # iter > 1 is single-frame only
+    ctx.close()
+
+
+def test_frame_batches_equal_the_frame_by_frame_sequence():
+    """aipt_frames (batched traces, denoiser passes in order, hidden state carried through the batch) == aipt_frame x n."""
+    import torch
+    W, H, depth = 80, 48, 4
+    sc, mats, faces, box = _mesh_scene((W, H), depth)
+    cams = [sc.orbit(phi=sc.phi + 0.1 * k) for k in range(7)]
+    blob = synth.make_blob(7)
+
+    def run(batch):
+        ctx = api.Context(0)
+        ctx.pathtrace_init(sc.geoms, mats, faces, box)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        outs = []
+        if batch == 1:
+            o = torch.empty(3, H, W, device="cuda")
+            for k, c in enumerate(cams):
+                ctx.frame(c, 1, depth, o, bn_batch=True, carry=k > 0)
+                ctx.sync()
+                outs.append(o.cpu().numpy().copy())
+        else:
+            ctx.frames_configure(batch)
+            ob = [torch.empty(3, H, W, device="cuda") for _ in range(batch)]
+            k = 0
+            while k < len(cams):
+                nb = min(batch, len(cams) - k)
+                ctx.frames(cams[k:k + nb], 1, depth, ob, bn_batch=True, carry_first=k > 0, carry=True)
+                ctx.sync()
+                outs += [ob[j].cpu().numpy().copy() for j in range(nb)]
+                k += nb
+        ctx.close()
+        return outs
+    ref = run(1)
+    for batch in (3, 4):
+        got = run(batch)
+        assert len(got) == len(ref)
+        for k in range(len(ref)):
+            assert np.array_equal(got[k], ref[k]), (batch, k)

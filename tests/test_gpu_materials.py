@@ -209,3 +209,39 @@ def test_motion_blur_moves_the_primitives(ctx):
     gpu_trace(ctx, sc, 4, iters=8, each_iter=lambda it, g: still.append(g.copy()))
     _same(still[2], got[2], "before the first move")
     assert not np.array_equal(still[7][0:3], got[7][0:3])
+
+
+# ------------------------------------------------------------------ full benchmark sizes against the oracle (CPU BVH, same result)
+def _full_size(ctx, sc, depth, what):
+    import oracle
+    g_ref, n_ref, m_ref = sc.pathtrace(flags=oracle.TRACE_AA | oracle.TRACE_COMPACT | oracle.TRACE_ORACLE_BVH)
+    g, n, mt = gpu_trace(ctx, sc, depth)
+    assert np.array_equal(mt, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist(), what
+    _same(g, g_ref, what)
+    return m_ref
+
+
+def test_configs2_diffuse_sponza_1280x720_bit_exact(ctx):
+    """BASELINE configs[2] as named: 262 144-triangle diffuse atrium, 1280x720, depth 8 -- every G-buffer bit against the oracle
+    (whose CPU BVH is checked against the reference's exhaustive loop in tests/test_oracle_trace.py)."""
+    sc = _cornell((1280, 720), 8)
+    first = add_materials(sc, [synth.STONE])
+    faces, lb, ub = synth.make_atrium_mesh(262144, 565, material=first)
+    sc.set_mesh(faces, lb, ub)
+    m = _full_size(ctx, sc, 8, "configs[2]")
+    assert (m == first).sum() > 100000
+
+
+def test_configs3_reflective_sponza_1280x720_bit_exact(ctx):
+    sc = _cornell((1280, 720), 8)
+    first = add_materials(sc, [synth.STONE, synth.MIRROR])
+    faces, lb, ub = synth.make_atrium_mesh(262144, 565, material=first, floor_material=first + 1, column_material=first + 1)
+    sc.set_mesh(faces, lb, ub)
+    m = _full_size(ctx, sc, 8, "configs[3]")
+    assert (m == first + 1).sum() > 100000
+
+
+def test_configs4_living_room_1920x1080_depth12_bit_exact(ctx):
+    sc = _living_room((1920, 1080), 12, 524288)
+    m = _full_size(ctx, sc, 12, "configs[4]")
+    assert {7, 8} <= set(np.unique(m).tolist())

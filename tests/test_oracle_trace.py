@@ -256,3 +256,24 @@ def test_reflective_material_arithmetic_is_finite_where_it_matters():
     L.orc_scatter(io.ctypes.data, hit.ctypes.data, C.byref(oracle.Material.from_buffer_copy(synth.MIRROR)), C.byref(rng))
     np.testing.assert_allclose(io[3:6], [0.6, 0.8, 0.0], atol=1e-6)
     np.testing.assert_allclose(io[6:9], [0.9, 0.9, 0.9], atol=0)
+
+
+def test_oracle_bvh_equals_the_exhaustive_face_loop():
+    """oracle/trace_bvh.c (flag TRACE_ORACLE_BVH) only accelerates the reference's loop over all faces: same G-buffer bits,
+    same live counts, same first-hit materials -- including coincident faces (lowest index wins) and mixed materials."""
+    from ai_path_tracer_denoiser_amd import synth
+    from tests.gpu_util import add_materials
+    fl = oracle.TRACE_AA | oracle.TRACE_COMPACT
+    sc = OracleScene.parse(CORNELL, res=(96, 64), depth=8)
+    faces, lb, ub, mats = synth.make_living_room_mesh(8192, 565, first_material=len(sc.materials))
+    add_materials(sc, mats)
+    dup = faces[:512].copy()
+    dup["materialid"] = len(sc.materials) - 1
+    sc.set_mesh(np.concatenate([faces, dup]), lb, ub)
+    g0, n0, m0 = sc.pathtrace(flags=fl)
+    g1, n1, m1 = sc.pathtrace(flags=fl | oracle.TRACE_ORACLE_BVH)
+    assert np.array_equal(g0.view(np.uint32), g1.view(np.uint32)) and np.array_equal(n0, n1) and np.array_equal(m0, m1)
+    sc2 = _mixed_scene((80, 60), 6)
+    g0, n0, m0 = sc2.pathtrace(flags=fl | oracle.TRACE_SORT_MATERIAL)
+    g1, n1, m1 = sc2.pathtrace(flags=fl | oracle.TRACE_SORT_MATERIAL | oracle.TRACE_ORACLE_BVH)
+    assert np.array_equal(g0.view(np.uint32), g1.view(np.uint32)) and np.array_equal(n0, n1) and np.array_equal(m0, m1)

@@ -111,6 +111,11 @@ ABI = [
     ("aipt_frame_set_timing", C.c_int, [_P, C.c_int]),
     ("aipt_frame_last_times", C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("aipt_frame_prefetch", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32]),
+    ("aipt_comm_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_int, C.POINTER(_P)]),
+    ("aipt_comm_is_rccl", C.c_int, [_P]),
+    ("aipt_comm_broadcast", C.c_int, [_P, C.POINTER(_P), C.c_size_t, C.c_int]),
+    ("aipt_comm_destroy", None, [_P]),
+    ("aipt_device_count", C.c_int, []),
     ("aipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     ("aipt_scene_release", None, [_P]),
     ("aipt_scene_set_resolution", C.c_int, [_P, C.c_int, C.c_int]),

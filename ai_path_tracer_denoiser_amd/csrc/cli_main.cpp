@@ -7,8 +7,18 @@
 // training/preprocess.py:37-41 un-scales them (colours x255, normals x100, depth x10), and optionally raw .npy tensors.
 //
 //   aiptd scene.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE | --synthetic-weights SEED]
-//                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3] [--pan AMPLITUDE] [--device I]
-//                   [--no-aa] [--no-compaction] [--dump-weights FILE]
+//                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w] [--pan AMPLITUDE] [--device I]
+//                   [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]
+//                   [--gpus N] [--ranks R] [--shim] [--batch B] [--reset-every C]
+//
+// Multi-GPU (no reference equivalent: the reference is single-GPU; design SURVEY 8e): --gpus N runs one rank (one
+// host thread, one context) per GPU; rank r renders the contiguous frame chunk [r*F/R, (r+1)*F/R) -- contiguous so that a
+// carried recurrent hidden state is valid inside a chunk; the first frame of a chunk starts from a zero hidden state.  Rank 0
+// parses the scene and builds the BVH ONCE (aipt_scene_pack); the packed scene and the weight blob are broadcast to the other
+// ranks' GPUs with RCCL (aipt_comm_*), nothing is exchanged per frame.  --ranks R > N puts several ranks on a GPU and
+// replaces RCCL by an in-process copy shim, so a one-GPU box can check that sharded rendering is byte-identical
+// (tests/test_cli.py); --reset-every C makes a single rank drop the hidden state where R ranks would (every C frames).
+// --batch B traces B consecutive frames with one set of launches (aipt_frames; identical results).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -16,6 +26,8 @@
 #include <cstring>
 #include <string>
 #include <sys/stat.h>
+#include <chrono>
+#include <thread>
 #include <vector>
 
 #include "../../include/aiptd.h"
@@ -170,147 +182,266 @@ int die(aipt_ctx* ctx, const char* what, int rc) {
     return 1;
 }
 
-}  // namespace
-
-int main(int argc, char** argv) {
-    if (argc < 2) {
-        printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
-               " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3]"
-               " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--dump-weights FILE]\n", argv[0]);
-        return 1;
-    }
-    std::string scene_path = argv[1], out_dir, weights_path, dump_weights;
+struct Options {
+    std::string scene_path, out_dir, weights_path, dump_weights;
     int frames = 1, res_w = 0, res_h = 0, depth = 0, device = 0, impl = AIPT_DN_IMPL_MFMA_F16X3;
+    int gpus = 1, ranks = 0, batch = 1, reset_every = 0;
+    bool npy = false, shim = false;
     uint64_t wseed = 565;
-    bool npy = false;
     uint32_t dn_flags = AIPT_DN_BN_BATCH | AIPT_DN_HIDDEN_CARRY, tr_flags = AIPT_TRACE_DEFAULT;
     float pan = 0.35f;
-    for (int i = 2; i < argc; i++) {
-        const std::string a = argv[i];
-        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "aiptd: %s needs %d value(s)\n", a.c_str(), n); exit(1); } };
-        if (a == "--frames") { need(1); frames = atoi(argv[++i]); }
-        else if (a == "--out") { need(1); out_dir = argv[++i]; }
-        else if (a == "--npy") npy = true;
-        else if (a == "--res") { need(2); res_w = atoi(argv[++i]); res_h = atoi(argv[++i]); }
-        else if (a == "--depth") { need(1); depth = atoi(argv[++i]); }
-        else if (a == "--weights") { need(1); weights_path = argv[++i]; }
-        else if (a == "--synthetic-weights") { need(1); wseed = strtoull(argv[++i], nullptr, 10); }
-        else if (a == "--dump-weights") { need(1); dump_weights = argv[++i]; }
-        else if (a == "--bn") { need(1); const std::string v = argv[++i]; dn_flags = (dn_flags & ~1u) | (v == "batch" ? AIPT_DN_BN_BATCH : AIPT_DN_BN_RUNNING); }
-        else if (a == "--hidden") { need(1); const std::string v = argv[++i]; dn_flags = (dn_flags & ~2u) | (v == "carry" ? AIPT_DN_HIDDEN_CARRY : AIPT_DN_HIDDEN_RESET); }
-        else if (a == "--impl") { need(1); impl = std::string(argv[++i]) == "f32" ? AIPT_DN_IMPL_MFMA : AIPT_DN_IMPL_MFMA_F16X3; }
-        else if (a == "--pan") { need(1); pan = (float)atof(argv[++i]); }
-        else if (a == "--device") { need(1); device = atoi(argv[++i]); }
-        else if (a == "--no-aa") tr_flags &= ~AIPT_TRACE_AA;
-        else if (a == "--no-compaction") tr_flags &= ~AIPT_TRACE_COMPACT;
-        else { fprintf(stderr, "aiptd: unknown option %s\n", a.c_str()); return 1; }
-    }
-    crc_init();
+};
 
-    std::vector<unsigned char> blob;
-    if (!weights_path.empty()) {
-        FILE* f = fopen(weights_path.c_str(), "rb");
-        if (!f) { fprintf(stderr, "aiptd: cannot open %s\n", weights_path.c_str()); return 1; }
-        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
-        blob.resize(n);
-        if (fread(blob.data(), 1, n, f) != (size_t)n) { fclose(f); return 1; }
-        fclose(f);
-    } else {
-        blob = make_synth_blob(wseed);          // the reference ships no trained weights
-    }
-    if (!dump_weights.empty()) {
-        FILE* f = fopen(dump_weights.c_str(), "wb");
-        if (!f || fwrite(blob.data(), 1, blob.size(), f) != blob.size()) { fprintf(stderr, "aiptd: cannot write %s\n", dump_weights.c_str()); return 1; }
-        fclose(f);
-        if (frames <= 0) return 0;
-    }
-
-    aipt_scene* scene = nullptr;
-    char err[512];
-    int rc = aipt_scene_load(scene_path.c_str(), &scene, err, sizeof(err));
-    if (rc) { fprintf(stderr, "aiptd: %s\n", err); return 1; }
-    if (res_w > 0 && res_h > 0) aipt_scene_set_resolution(scene, res_w, res_h);
-    int ngeoms, nmats, nfaces, iterations, scene_depth;
-    aipt_scene_info(scene, &ngeoms, &nmats, &nfaces, &iterations, &scene_depth);
-    if (depth <= 0) depth = scene_depth;
-    aipt_camera cam0;
-    aipt_scene_camera(scene, &cam0);
-    float zoom, phi0, theta;
-    aipt_scene_orbit_params(scene, &zoom, &phi0, &theta);
-    const int W = cam0.resolution[0], H = cam0.resolution[1];
-    printf("aiptd: %s: %d primitives, %d materials, %d faces; %dx%d depth %d; %d frame(s)\n", scene_path.c_str(), ngeoms,
-           nmats, nfaces, W, H, depth, frames);
-
+struct Rank {
+    int id = 0, device = 0, f0 = 0, f1 = 0;
     aipt_ctx* ctx = nullptr;
-    rc = aipt_create(device, nullptr, &ctx);
-    if (rc) { fprintf(stderr, "aiptd: %s\n", aipt_last_error(nullptr)); return 1; }
-    if ((rc = aipt_scene_upload_host(ctx, scene))) return die(ctx, "aipt_scene_upload_host", rc);
-    if ((rc = aipt_denoise_load_weights(ctx, blob.data(), blob.size()))) return die(ctx, "aipt_denoise_load_weights", rc);
-    if ((rc = aipt_frame_configure(ctx, W, H))) return die(ctx, "aipt_frame_configure", rc);
-    if ((rc = aipt_denoise_set_impl(ctx, impl))) return die(ctx, "aipt_denoise_set_impl", rc);
-    float* d_out = nullptr;
-    if ((rc = aipt_malloc(ctx, sizeof(float) * 3 * W * H, (void**)&d_out))) return die(ctx, "aipt_malloc", rc);
+    double ms_total = 0, sum_t = 0, sum_d = 0;
+    int timed = 0;
+    std::string err;
+};
+
+struct Shared {
+    Options o;
+    aipt_camera cam0;
+    float zoom, phi0, theta;
+    int W, H, depth;
+};
+
+// one rank's share of the frame sequence: frames [f0, f1), file names by global frame index
+void render(const Shared& sh, Rank& rk) {
+    const Options& o = sh.o;
+    aipt_ctx* ctx = rk.ctx;
+    const int W = sh.W, H = sh.H, B = o.batch;
+    auto fail = [&](const char* what, int rc) {
+        char buf[640];
+        snprintf(buf, sizeof(buf), "rank %d: %s failed (%d): %s", rk.id, what, rc, aipt_last_error(ctx));
+        rk.err = buf;
+    };
+    int rc;
+    std::vector<float*> d_out(B, nullptr);
+    for (int j = 0; j < B; j++)
+        if ((rc = aipt_malloc(ctx, sizeof(float) * 3 * W * H, (void**)&d_out[j]))) return fail("aipt_malloc", rc);
     float* d_gbuf; int rows, stride;
     aipt_gbuffer(ctx, &d_gbuf, &rows, &stride);
     const size_t plane = (size_t)rows * stride;
     std::vector<float> h_g(10 * plane), h_o((size_t)3 * W * H);
-    const bool save = !out_dir.empty();
-    if (save) {
-        mkdir(out_dir.c_str(), 0755);
-        for (const char* d : {"RGB", "Normals", "Depth", "Albedos", "Denoised"}) mkdir((out_dir + "/" + d).c_str(), 0755);
-    }
+    const bool save = !o.out_dir.empty();
     aipt_frame_set_timing(ctx, 1);
-    double sum_t = 0, sum_d = 0;
-    aipt_timer_start(ctx);
-    for (int k = 0; k < frames; k++) {
-        aipt_camera cam = cam0;
-        const float phi = phi0 + pan * std::sin(2.0 * 3.14159265358979323846 * k / 300.0);   // build-defined pan
-        aipt_camera_orbit(&cam, zoom, phi, theta);
-        uint32_t f = dn_flags;
-        if (k == 0) f &= ~AIPT_DN_HIDDEN_CARRY;
-        if ((rc = aipt_frame(ctx, &cam, 1, depth, tr_flags, f, d_out))) return die(ctx, "aipt_frame", rc);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = rk.f0; k < rk.f1;) {
+        // frames of this call: up to B, not across a hidden-state reset
+        int nb = std::min(B, rk.f1 - k);
+        if (o.reset_every > 0) nb = std::min(nb, o.reset_every - k % o.reset_every);
+        std::vector<aipt_camera> cams(nb, sh.cam0);
+        for (int j = 0; j < nb; j++) {
+            const float phi = sh.phi0 + o.pan * std::sin(2.0 * 3.14159265358979323846 * (k + j) / 300.0);   // build-defined pan
+            aipt_camera_orbit(&cams[j], sh.zoom, phi, sh.theta);
+        }
+        uint32_t f_first = o.dn_flags;
+        if (k == rk.f0 || (o.reset_every > 0 && k % o.reset_every == 0)) f_first &= ~AIPT_DN_HIDDEN_CARRY;   // chunk start
+        if (B > 1) rc = aipt_frames(ctx, cams.data(), nb, 1, sh.depth, o.tr_flags, f_first, o.dn_flags, d_out.data());
+        else rc = aipt_frame(ctx, &cams[0], 1, sh.depth, o.tr_flags, f_first, d_out[0]);
+        if (rc) return fail(B > 1 ? "aipt_frames" : "aipt_frame", rc);
         if (save) {
             float tms, dms;
             aipt_frame_last_times(ctx, &tms, &dms);
-            sum_t += tms; sum_d += dms;
+            rk.sum_t += tms * nb; rk.sum_d += dms * nb; rk.timed += nb;
+        }
+        for (int j = 0; j < nb && save; j++) {
+            if (B > 1) aipt_frames_gbuffer(ctx, j, &d_gbuf, &rows, &stride);
             aipt_download(ctx, h_g.data(), d_gbuf, sizeof(float) * h_g.size());
-            aipt_download(ctx, h_o.data(), d_out, sizeof(float) * h_o.size());
+            aipt_download(ctx, h_o.data(), d_out[j], sizeof(float) * h_o.size());
             char name[64];
-            snprintf(name, sizeof(name), "/frame_%04d", k);
+            snprintf(name, sizeof(name), "/frame_%04d", k + j);
             const auto rgb = to_image(h_g.data(), plane, stride, W, H, 3, 255.0f);
             const auto nrm = to_image(h_g.data() + 3 * plane, plane, stride, W, H, 3, 100.0f);
             const auto dep = to_image(h_g.data() + 6 * plane, plane, stride, W, H, 1, 10.0f);
             const auto alb = to_image(h_g.data() + 7 * plane, plane, stride, W, H, 3, 255.0f);
             const auto den = to_image(h_o.data(), (size_t)W * H, W, W, H, 3, 255.0f);
-            bool ok = write_png(out_dir + "/RGB" + name + ".png", rgb.data(), W, H, 3) &&
-                      write_png(out_dir + "/Normals" + name + ".png", nrm.data(), W, H, 3) &&
-                      write_png(out_dir + "/Depth" + name + ".png", dep.data(), W, H, 1) &&
-                      write_png(out_dir + "/Albedos" + name + ".png", alb.data(), W, H, 3) &&
-                      write_png(out_dir + "/Denoised" + name + ".png", den.data(), W, H, 3);
-            if (npy) {
+            bool ok = write_png(o.out_dir + "/RGB" + name + ".png", rgb.data(), W, H, 3) &&
+                      write_png(o.out_dir + "/Normals" + name + ".png", nrm.data(), W, H, 3) &&
+                      write_png(o.out_dir + "/Depth" + name + ".png", dep.data(), W, H, 1) &&
+                      write_png(o.out_dir + "/Albedos" + name + ".png", alb.data(), W, H, 3) &&
+                      write_png(o.out_dir + "/Denoised" + name + ".png", den.data(), W, H, 3);
+            if (o.npy) {
                 // the G-buffer with its padding stripped: [10][H][W]
                 std::vector<float> g((size_t)10 * W * H);
                 for (int c = 0; c < 10; c++)
                     for (int y = 0; y < H; y++)
                         memcpy(&g[((size_t)c * H + y) * W], &h_g[c * plane + (size_t)y * stride], sizeof(float) * W);
-                ok = ok && write_npy(out_dir + name + "_gbuffer.npy", g.data(), 10, H, W) &&
-                     write_npy(out_dir + name + "_denoised.npy", h_o.data(), 3, H, W);
+                ok = ok && write_npy(o.out_dir + name + "_gbuffer.npy", g.data(), 10, H, W) &&
+                     write_npy(o.out_dir + name + "_denoised.npy", h_o.data(), 3, H, W);
             }
-            if (!ok) { fprintf(stderr, "aiptd: cannot write frame %d under %s\n", k, out_dir.c_str()); return 1; }
+            if (!ok) { rk.err = "cannot write frame under " + o.out_dir; return; }
         }
+        k += nb;
     }
-    float total_ms = 0;
-    aipt_timer_stop(ctx, &total_ms);
-    if (!save) {
+    aipt_sync(ctx);
+    rk.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!save && rk.f1 > rk.f0) {
         float tms, dms;
         aipt_frame_last_times(ctx, &tms, &dms);
-        sum_t = tms * frames; sum_d = dms * frames;
+        rk.sum_t = tms; rk.sum_d = dms; rk.timed = 1;
+    }
+    for (float* p : d_out) aipt_free(ctx, p);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
+               " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w]"
+               " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]"
+               " [--gpus N] [--ranks R] [--shim] [--batch B] [--reset-every C]\n", argv[0]);
+        return 1;
+    }
+    Shared sh;
+    Options& o = sh.o;
+    o.scene_path = argv[1];
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](int n) { if (i + n >= argc) { fprintf(stderr, "aiptd: %s needs %d value(s)\n", a.c_str(), n); exit(1); } };
+        if (a == "--frames") { need(1); o.frames = atoi(argv[++i]); }
+        else if (a == "--out") { need(1); o.out_dir = argv[++i]; }
+        else if (a == "--npy") o.npy = true;
+        else if (a == "--res") { need(2); o.res_w = atoi(argv[++i]); o.res_h = atoi(argv[++i]); }
+        else if (a == "--depth") { need(1); o.depth = atoi(argv[++i]); }
+        else if (a == "--weights") { need(1); o.weights_path = argv[++i]; }
+        else if (a == "--synthetic-weights") { need(1); o.wseed = strtoull(argv[++i], nullptr, 10); }
+        else if (a == "--dump-weights") { need(1); o.dump_weights = argv[++i]; }
+        else if (a == "--bn") { need(1); const std::string v = argv[++i]; o.dn_flags = (o.dn_flags & ~1u) | (v == "batch" ? AIPT_DN_BN_BATCH : AIPT_DN_BN_RUNNING); }
+        else if (a == "--hidden") { need(1); const std::string v = argv[++i]; o.dn_flags = (o.dn_flags & ~2u) | (v == "carry" ? AIPT_DN_HIDDEN_CARRY : AIPT_DN_HIDDEN_RESET); }
+        else if (a == "--impl") {
+            need(1);
+            const std::string v = argv[++i];
+            o.impl = v == "f32" ? AIPT_DN_IMPL_MFMA : v == "f16w" ? AIPT_DN_IMPL_MFMA_F16W : AIPT_DN_IMPL_MFMA_F16X3;
+        }
+        else if (a == "--pan") { need(1); o.pan = (float)atof(argv[++i]); }
+        else if (a == "--device") { need(1); o.device = atoi(argv[++i]); }
+        else if (a == "--no-aa") o.tr_flags &= ~AIPT_TRACE_AA;
+        else if (a == "--no-compaction") o.tr_flags &= ~AIPT_TRACE_COMPACT;
+        else if (a == "--sort-material") o.tr_flags |= AIPT_TRACE_SORT_MATERIAL;
+        else if (a == "--gpus") { need(1); o.gpus = atoi(argv[++i]); }
+        else if (a == "--ranks") { need(1); o.ranks = atoi(argv[++i]); }
+        else if (a == "--shim") o.shim = true;
+        else if (a == "--batch") { need(1); o.batch = atoi(argv[++i]); }
+        else if (a == "--reset-every") { need(1); o.reset_every = atoi(argv[++i]); }
+        else { fprintf(stderr, "aiptd: unknown option %s\n", a.c_str()); return 1; }
+    }
+    if (o.ranks <= 0) o.ranks = o.gpus;
+    if (o.gpus < 1 || o.ranks < o.gpus || o.batch < 1 || o.batch > 8) { fprintf(stderr, "aiptd: bad --gpus/--ranks/--batch\n"); return 1; }
+    crc_init();
+
+    std::vector<unsigned char> blob;
+    if (!o.weights_path.empty()) {
+        FILE* f = fopen(o.weights_path.c_str(), "rb");
+        if (!f) { fprintf(stderr, "aiptd: cannot open %s\n", o.weights_path.c_str()); return 1; }
+        fseek(f, 0, SEEK_END); const long n = ftell(f); fseek(f, 0, SEEK_SET);
+        blob.resize(n);
+        if (fread(blob.data(), 1, n, f) != (size_t)n) { fclose(f); return 1; }
+        fclose(f);
+    } else {
+        blob = make_synth_blob(o.wseed);          // the reference ships no trained weights
+    }
+    if (!o.dump_weights.empty()) {
+        FILE* f = fopen(o.dump_weights.c_str(), "wb");
+        if (!f || fwrite(blob.data(), 1, blob.size(), f) != blob.size()) { fprintf(stderr, "aiptd: cannot write %s\n", o.dump_weights.c_str()); return 1; }
+        fclose(f);
+        if (o.frames <= 0) return 0;
+    }
+
+    aipt_scene* scene = nullptr;
+    char err[512];
+    int rc = aipt_scene_load(o.scene_path.c_str(), &scene, err, sizeof(err));
+    if (rc) { fprintf(stderr, "aiptd: %s\n", err); return 1; }
+    if (o.res_w > 0 && o.res_h > 0) aipt_scene_set_resolution(scene, o.res_w, o.res_h);
+    int ngeoms, nmats, nfaces, iterations, scene_depth;
+    aipt_scene_info(scene, &ngeoms, &nmats, &nfaces, &iterations, &scene_depth);
+    sh.depth = o.depth > 0 ? o.depth : scene_depth;
+    aipt_scene_camera(scene, &sh.cam0);
+    aipt_scene_orbit_params(scene, &sh.zoom, &sh.phi0, &sh.theta);
+    sh.W = sh.cam0.resolution[0]; sh.H = sh.cam0.resolution[1];
+    const int W = sh.W, H = sh.H, R = o.ranks;
+    printf("aiptd: %s: %d primitives, %d materials, %d faces; %dx%d depth %d; %d frame(s) on %d rank(s) / %d GPU(s)\n",
+           o.scene_path.c_str(), ngeoms, nmats, nfaces, W, H, sh.depth, o.frames, R, o.gpus);
+
+    const int ndev = aipt_device_count();
+    if (o.device + o.gpus > ndev) {
+        fprintf(stderr, "aiptd: --gpus %d from device %d requested, %d GPU(s) visible; refusing to run on fewer\n", o.gpus, o.device, ndev);
+        return 1;
+    }
+    std::vector<Rank> ranks(R);
+    std::vector<aipt_ctx*> ctxs(R);
+    for (int r = 0; r < R; r++) {
+        ranks[r].id = r; ranks[r].device = o.device + r % o.gpus;
+        ranks[r].f0 = (int)((long)o.frames * r / R); ranks[r].f1 = (int)((long)o.frames * (r + 1) / R);
+        if ((rc = aipt_create(ranks[r].device, nullptr, &ranks[r].ctx))) { fprintf(stderr, "aiptd: %s\n", aipt_last_error(nullptr)); return 1; }
+        ctxs[r] = ranks[r].ctx;
+    }
+    // rank 0: pack the scene (the BVH is built here, once); broadcast scene + weights; every rank uploads its copy
+    void* scene_blob = nullptr; size_t scene_bytes = 0;
+    rc = aipt_scene_pack(aipt_scene_geoms(scene), ngeoms, aipt_scene_materials(scene), nmats, aipt_scene_faces(scene), nfaces,
+                         aipt_scene_mesh_box(scene), &scene_blob, &scene_bytes, err, sizeof(err));
+    if (rc) { fprintf(stderr, "aiptd: %s\n", err); return 1; }
+    bool rccl = false;
+    if (R > 1) {
+        aipt_comm* comm = nullptr;
+        if ((rc = aipt_comm_create(ctxs.data(), R, o.shim ? 1 : 0, &comm))) return die(ctxs[0], "aipt_comm_create", rc);
+        rccl = aipt_comm_is_rccl(comm) != 0;
+        const struct { const void* src; size_t bytes; } parts[2] = {{scene_blob, scene_bytes}, {blob.data(), blob.size()}};
+        std::vector<std::vector<unsigned char>> got[2];
+        for (int part = 0; part < 2; part++) {
+            std::vector<void*> d(R, nullptr);
+            for (int r = 0; r < R; r++) if ((rc = aipt_malloc(ctxs[r], parts[part].bytes, &d[r]))) return die(ctxs[r], "aipt_malloc", rc);
+            if ((rc = aipt_upload(ctxs[0], d[0], parts[part].src, parts[part].bytes))) return die(ctxs[0], "aipt_upload", rc);
+            if ((rc = aipt_comm_broadcast(comm, d.data(), parts[part].bytes, 0))) return die(ctxs[0], "aipt_comm_broadcast", rc);
+            got[part].resize(R);
+            for (int r = 0; r < R; r++) {
+                got[part][r].resize(parts[part].bytes);
+                if ((rc = aipt_download(ctxs[r], got[part][r].data(), d[r], parts[part].bytes))) return die(ctxs[r], "aipt_download", rc);
+                aipt_free(ctxs[r], d[r]);
+            }
+        }
+        aipt_comm_destroy(comm);
+        for (int r = 0; r < R; r++) {                             // every rank takes what the broadcast delivered to ITS GPU
+            if ((rc = aipt_scene_upload_packed(ctxs[r], got[0][r].data(), got[0][r].size()))) return die(ctxs[r], "aipt_scene_upload_packed", rc);
+            if ((rc = aipt_denoise_load_weights(ctxs[r], got[1][r].data(), got[1][r].size()))) return die(ctxs[r], "aipt_denoise_load_weights", rc);
+        }
+    } else {
+        if ((rc = aipt_scene_upload_packed(ctxs[0], scene_blob, scene_bytes))) return die(ctxs[0], "aipt_scene_upload_packed", rc);
+        if ((rc = aipt_denoise_load_weights(ctxs[0], blob.data(), blob.size()))) return die(ctxs[0], "aipt_denoise_load_weights", rc);
+    }
+    aipt_blob_free(scene_blob);
+    for (int r = 0; r < R; r++) {
+        if ((rc = aipt_frame_configure(ctxs[r], W, H))) return die(ctxs[r], "aipt_frame_configure", rc);
+        if (o.batch > 1 && (rc = aipt_frames_configure(ctxs[r], o.batch))) return die(ctxs[r], "aipt_frames_configure", rc);
+        if ((rc = aipt_denoise_set_impl(ctxs[r], o.impl))) return die(ctxs[r], "aipt_denoise_set_impl", rc);
+    }
+    if (!o.out_dir.empty()) {
+        mkdir(o.out_dir.c_str(), 0755);
+        for (const char* d : {"RGB", "Normals", "Depth", "Albedos", "Denoised"}) mkdir((o.out_dir + "/" + d).c_str(), 0755);
+    }
+    // one host thread per rank (SURVEY 8b "Threading": one ctx per GPU, one host thread per ctx)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (R == 1) render(sh, ranks[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < R; r++) th.emplace_back(render, std::cref(sh), std::ref(ranks[r]));
+        for (auto& t : th) t.join();
+    }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    double sum_t = 0, sum_d = 0;
+    int timed = 0;
+    for (Rank& rk : ranks) {
+        if (!rk.err.empty()) { fprintf(stderr, "aiptd: %s\n", rk.err.c_str()); return 1; }
+        sum_t += rk.sum_t; sum_d += rk.sum_d; timed += rk.timed;
     }
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"depth\": %d, \"frames_per_s\": %.3f, \"ms_trace\": %.4f, "
-           "\"ms_denoise\": %.4f, \"includes_file_output\": %s}\n", frames, W, H, depth, frames / (total_ms * 1e-3),
-           sum_t / frames, sum_d / frames, save ? "true" : "false");
-    aipt_free(ctx, d_out);
-    aipt_destroy(ctx);
+           "\"ms_denoise\": %.4f, \"ranks\": %d, \"gpus\": %d, \"broadcast\": \"%s\", \"batch\": %d, \"includes_file_output\": %s}\n",
+           o.frames, W, H, sh.depth, o.frames / (wall_ms * 1e-3), timed ? sum_t / timed : 0.0, timed ? sum_d / timed : 0.0, R, o.gpus,
+           R == 1 ? "none" : rccl ? "rccl" : "in-process shim", o.batch, o.out_dir.empty() ? "false" : "true");
+    for (Rank& rk : ranks) aipt_destroy(rk.ctx);
     aipt_scene_release(scene);
     return 0;
 }

@@ -255,6 +255,20 @@ int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
 int aipt_frame_set_timing(aipt_ctx* ctx, int enabled);
 int aipt_frame_last_times(aipt_ctx* ctx, float* trace_ms, float* denoise_ms);
 
+/* ---- multi-GPU hosts: the one-time broadcast (no reference equivalent: single GPU) ------------------------------ */
+/* The path shards by frames (one context per GPU, contiguous frame chunks, no per-frame exchange); the only collective is
+ * rank 0's packed scene (aipt_scene_pack: geometry + the BVH built once) and weight blob going to every rank.
+ * aipt_comm_create over n contexts: RCCL (ncclCommInitAll, grouped ncclBroadcast over xGMI; librccl is dlopen'ed) when every
+ * context has its own GPU, an in-process copy shim when contexts share a GPU or force_shim != 0 (`aiptd --gpus 1 --ranks 8`).
+ * aipt_comm_broadcast: d_bufs[r] = device buffer of `bytes` bytes in context r; after the call all hold root's bytes
+ * (synchronous).  Single host thread. */
+typedef struct aipt_comm aipt_comm;
+int  aipt_comm_create(aipt_ctx* const* ctxs, int n, int force_shim, aipt_comm** out);
+int  aipt_comm_is_rccl(const aipt_comm* comm);
+int  aipt_comm_broadcast(aipt_comm* comm, void* const* d_bufs, size_t bytes, int root);
+void aipt_comm_destroy(aipt_comm* comm);
+int  aipt_device_count(void);
+
 /* ---- host-side scene front end (scene.cpp:11-320, utilities.cpp:45-52, main.cpp:66-78,122-140) -------------- */
 typedef struct aipt_scene aipt_scene;
 /* Parses the reference's scene grammar (MATERIAL / OBJECT / CAMERA / MESH blocks), builds the three matrices of every

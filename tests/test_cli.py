@@ -54,3 +54,58 @@ def test_cli_frame_sequence_outputs(tmp_path):
     y_ref = orc.forward(g_ref, True, False)
     y = np.load(out / "frame_0000_denoised.npy")
     assert np.abs(y - y_ref).max() <= 1e-3
+
+
+# ------------------------------------------------------------------ multi-rank host (aiptd --gpus N --ranks R), SURVEY 8e
+def _mesh_scene_file(tmp_path, ntri=2048):
+    """cornell.txt + a MESH block (reference grammar, scenes/Scenes/cornell_mesh.txt:128-133) pointing at a generated OBJ"""
+    faces, _, _ = synth.make_atrium_mesh(ntri, 565, material=0)
+    synth.write_obj(str(tmp_path / "atrium.obj"), faces)
+    txt = open(CORNELL).read().rstrip() + "\n\nMESH 0\nPATH atrium.obj\nmaterial 1\nTRANS       0 0 0\nROTAT       0 0 0\nSCALE       1 1 1\n"
+    p = tmp_path / "cornell_mesh.txt"
+    p.write_text(txt)
+    return str(p)
+
+
+def _run_cli(scene, out, *extra):
+    r = subprocess.run([CLI, scene, "--res", "96", "64", "--depth", "4", "--out", str(out), "--npy"] + list(extra),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _frames(out, n):
+    return [(np.load(out / f"frame_{k:04d}_gbuffer.npy"), np.load(out / f"frame_{k:04d}_denoised.npy")) for k in range(n)]
+
+
+@pytest.mark.gpu
+def test_cli_ranks_sharing_one_gpu_render_byte_identical_frames(tmp_path):
+    """`--gpus 1 --ranks R` (in-process broadcast shim, contiguous frame chunks, one host thread per rank) writes the frames a
+    single rank writes, byte for byte: hidden reset per frame = the shipped TorchScript semantics, where frames
+    are independent; hidden carried = a single rank that resets where the chunks start (--reset-every)."""
+    scene = _mesh_scene_file(tmp_path)
+    one = _run_cli(scene, tmp_path / "r1", "--frames", "8", "--hidden", "reset")
+    four = _run_cli(scene, tmp_path / "r4", "--frames", "8", "--hidden", "reset", "--gpus", "1", "--ranks", "4")
+    assert one["ranks"] == 1 and four["ranks"] == 4 and four["broadcast"] == "in-process shim"
+    for (g1, d1), (g4, d4) in zip(_frames(tmp_path / "r1", 8), _frames(tmp_path / "r4", 8)):
+        assert np.array_equal(g1.view(np.uint32), g4.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d4.view(np.uint32))
+    _run_cli(scene, tmp_path / "c1", "--frames", "8", "--hidden", "carry", "--reset-every", "4")
+    _run_cli(scene, tmp_path / "c2", "--frames", "8", "--hidden", "carry", "--gpus", "1", "--ranks", "2")
+    for (g1, d1), (g2, d2) in zip(_frames(tmp_path / "c1", 8), _frames(tmp_path / "c2", 8)):
+        assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    # and the carried run differs from the reset run after the first frame of a chunk (the state really is carried)
+    assert not np.array_equal(_frames(tmp_path / "c1", 2)[1][1], _frames(tmp_path / "r1", 2)[1][1])
+
+
+@pytest.mark.gpu
+def test_cli_batched_frames_and_gpu_count_check(tmp_path):
+    scene = _mesh_scene_file(tmp_path)
+    _run_cli(scene, tmp_path / "b1", "--frames", "7", "--hidden", "carry")
+    b3 = _run_cli(scene, tmp_path / "b3", "--frames", "7", "--hidden", "carry", "--batch", "3")
+    assert b3["batch"] == 3
+    for (g1, d1), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / "b3", 7)):
+        assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([CLI, scene, "--frames", "2", "--gpus", str(n + 1)], capture_output=True, text=True)
+    assert r.returncode == 1 and "refusing to run on fewer" in r.stderr            # never silently fewer GPUs than asked for

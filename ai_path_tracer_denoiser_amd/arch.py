@@ -164,6 +164,28 @@ def blob_from_state_dict(sd) -> bytes:
     return pack_blob(params)
 
 
+def state_dict_from_file(path: str):
+    """The reference's two weight containers -> state_dict:
+    * a TorchScript archive as training/convert_to_torchscript.py:29-30 saves it (torch.jit.trace(model.forward).save(...),
+      the file the C++ host loads with torch::jit::load, main.cpp:107): the traced module keeps the model's parameter and
+      buffer names, so torch.jit.load(path).state_dict() is the state_dict;
+    * a training checkpoint ``{'net': state_dict}`` (training/train.py:109-112), or a bare state_dict."""
+    import torch
+    try:
+        return torch.jit.load(path, map_location="cpu").state_dict()
+    except RuntimeError:
+        pass
+    ck = torch.load(path, map_location="cpu")
+    if isinstance(ck, dict) and "net" in ck:
+        ck = ck["net"]
+    return ck
+
+
+def blob_from_file(path: str) -> bytes:
+    """TorchScript archive or ``{'net': ...}`` checkpoint -> flat weight blob (tools/export_weights.py)."""
+    return blob_from_state_dict(state_dict_from_file(path))
+
+
 def state_dict_from_params(params):
     """Inverse mapping (numpy arrays keyed by the reference's state_dict names); used only
     by the golden-vector generator to load our synthetic weights into the reference model."""

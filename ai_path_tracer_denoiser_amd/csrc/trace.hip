@@ -23,7 +23,9 @@
 // bit.  sin/cos of the hemisphere angle use the same Cody-Waite + minimax polynomial on both sides (det_sincosf).
 #include "internal.h"
 
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 
 namespace aipt {
@@ -117,7 +119,16 @@ struct TraceParams {
     int* hist; int nkeys, nblk;
     const int* sort_in; int* sort_out;
     int* stack_ovf;                 // [stack bound - STACK_LDS][P] traversal-stack overflow (see WalkStack)
+    int rpw32_below, rpw16_below;   // rays_per_wave thresholds
 };
+
+// Rays per wave of a later bounce.  A wave runs the UNION of its lanes' walks (tools/trace_stats.py: ~50 node steps per wave for
+// ~7 per ray), and a launch lasts as long as its slowest wave; when a bounce has too few live paths to fill the chip anyway,
+// its waves take 32 or 16 paths each instead of 64: shorter unions, more waves, same total work.  A pure function of the live
+// count, so the bounce kernel and trace_compact agree on the slot -> thread map without talking to the host.
+__device__ __forceinline__ int rays_per_wave(const TraceParams& p, int n) {
+    return n < p.rpw16_below ? 16 : (n < p.rpw32_below ? 32 : 64);
+}
 
 // ---------------------------------------------------------------------------------------------- vector helpers
 __device__ __forceinline__ v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -273,11 +284,13 @@ __device__ float triangleTest(const DevFace& f, v3 orig, v3 dir, v3& P, v3& N) {
 // Broad phase: can the ray touch the primitive's padded world box at all?  Conservative by construction -- the box is
 // padded by 1e-3 of its scale on the host, the slab arithmetic here is good to 3e-7 relative, NaNs answer "maybe" -- so
 // a primitive it rejects is one whose exact test returns "no hit", and skipping that test changes no result bit.
-__device__ __forceinline__ bool maybe_hits(const float* lo, const float* hi, v3 o, v3 inv) {
+// tn receives the distance at which the ray enters the padded box (a lower bound of any hit distance the exact test can
+// return for this primitive: the exact hit point lies inside the padded box).
+__device__ __forceinline__ bool maybe_hits(const float* lo, const float* hi, v3 o, v3 inv, float& tn) {
     const float t1 = (lo[0] - o.x) * inv.x, t2 = (hi[0] - o.x) * inv.x;
     const float t3 = (lo[1] - o.y) * inv.y, t4 = (hi[1] - o.y) * inv.y;
     const float t5 = (lo[2] - o.z) * inv.z, t6 = (hi[2] - o.z) * inv.z;
-    const float tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
     const float tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
     return !(tf < 0.0f || tn > tf);
 }
@@ -394,13 +407,30 @@ __device__ __forceinline__ float triHitT(v3 v0, v3 e1, v3 e2, v3 orig, v3 dir) {
 
 // -DAIPT_TRACE_STATS: walk statistics for tools/trace_stats.py (lane-level node visits and triangle tests, wave-level loop
 // trips); compiled out of the product build.
+#if defined(AIPT_TRACE_PHASES) && !defined(AIPT_TRACE_STATS)      // phase stamps alone: the walk counters perturb the timing
+#define AIPT_TRACE_STATS
+#define AIPT_TRACE_NO_COUNTERS
+#endif
 #ifdef AIPT_TRACE_STATS
 __device__ unsigned long long g_trace_stats[16];
+#ifdef AIPT_TRACE_NO_COUNTERS
+#define STAT_ADD(k, v) do {} while (0)
+#else
 #define STAT_ADD(k, v) atomicAdd(&g_trace_stats[k], (unsigned long long)(v))
+#endif
+__device__ unsigned long long g_phase[8];
+#define PHASE(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) atomicAdd(&g_phase[k], now_ - ph_t); ph_t = now_; } while (0)
+#define PHASE_INIT() unsigned long long ph_t = __builtin_amdgcn_s_memtime()
+#ifdef AIPT_TRACE_NO_COUNTERS
+#define STAT_WAVE(k) do {} while (0)
+#else
 #define STAT_WAVE(k) do { if (__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63)) atomicAdd(&g_trace_stats[k], 1ull); } while (0)
+#endif
 #else
 #define STAT_ADD(k, v) do {} while (0)
 #define STAT_WAVE(k) do {} while (0)
+#define PHASE(k) do {} while (0)
+#define PHASE_INIT() do {} while (0)
 #endif
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyteK
@@ -504,7 +534,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
                 if (key[2] < INFINITY) st.lds[st.sp++ * 256] = ref[2];
                 if (key[1] < INFINITY) st.lds[st.sp++ * 256] = ref[1];
             }
-#ifdef AIPT_TRACE_STATS
+#if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
             atomicMax(&g_trace_stats[6], (unsigned long long)st.sp);
             if (st.sp > 8) STAT_ADD(7, 1);
             if (st.sp > 12) STAT_ADD(15, 1);
@@ -541,7 +571,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
         cur = st.sp ? st.pop() : DONE;
         if (cur == DONE) break;
     }
-#ifdef AIPT_TRACE_STATS
+#if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
     atomicMax(&g_trace_stats[5], (unsigned long long)my_visits);
     const int bucket = my_visits <= 4 ? 8 : my_visits <= 8 ? 9 : my_visits <= 16 ? 10 : my_visits <= 32 ? 11 : my_visits <= 64 ? 12 : my_visits <= 128 ? 13 : 14;
     atomicAdd(&g_trace_stats[bucket], 1ull);
@@ -562,6 +592,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0));
     aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PHASE_INIT();
     const int P = p.P;
     float4* S0 = p.st; float4* S1 = p.st + p.PS; float4* S2 = p.st + 2 * p.PS;
 
@@ -571,16 +602,18 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     // every wave is full of live paths and the state planes are gathered/scattered through the pixel index.
     int i, idx, rem = 0;
     bool alive;
-    const int t = blockIdx.x * 256 + tid;
+    int t = blockIdx.x * 256 + tid;
     if (FIRST) {
         i = t; idx = t; alive = t < p.PT; rem = p.trace_depth;
     } else {
         const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
-        if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
+        const int rpw = rays_per_wave(p, n);
+        if ((int)(blockIdx.x * 4 * rpw) >= n) {        // whole workgroup beyond the list
             if (tid == 0) p.cnt[blockIdx.x] = 0;
             return;
         }
-        alive = t < n;
+        t = (blockIdx.x * 4 + wave) * rpw + lane;
+        alive = lane < rpw && t < n;
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
     }
@@ -609,6 +642,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
     }
     __syncthreads();
+    PHASE(0);
 
     bool alive_after = false;
     if (alive) {
@@ -651,23 +685,45 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             t_min = c[0]; materialid = __float_as_int(c[(size_t)P]);
             hitP = V(c[(size_t)2 * P], c[(size_t)3 * P], c[(size_t)4 * P]);
             normal = V(c[(size_t)5 * P], c[(size_t)6 * P], c[(size_t)7 * P]);
+        } else if (p.flags & 0x20000000u) {
+            t_min = 5.0f; materialid = 1; hitP = vadd(o, vscale(d, 5.0f)); normal = V(0, 1, 0);      // (timing ablation)
         } else if (broad) {
             // broad phase over all primitives (wave-uniform loop, scalar loads), then the exact tests on this lane's
             // candidates only, in index order (so "the first of equal distances wins" as in the reference's loop): a
             // wave runs max-over-lanes(candidates) exact tests instead of ngeoms
+            // The exact test of the candidate whose padded box the ray enters FIRST runs first; every other candidate whose box
+            // is entered clearly beyond that hit is skipped -- its exact test could only return a larger distance, which never
+            // wins -- so a wave runs ~1 box and ~1 sphere test instead of max-over-lanes(candidates) of each (the exact tests
+            // were 39 % of the bounce kernel's wave cycles on the mesh scene).  Equal distances resolve by index as in the loop.
             const v3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
             unsigned cand = 0;
-            for (int gi = 0; gi < p.ngeoms; gi++)
-                if (maybe_hits(p.geoms[gi].lo, p.geoms[gi].hi, o, inv)) cand |= 1u << gi;
+            float near_tn = INFINITY;
+            int near_g = -1;
+            for (int gi = 0; gi < p.ngeoms; gi++) {
+                float tn;
+                if (maybe_hits(p.geoms[gi].lo, p.geoms[gi].hi, o, inv, tn)) {
+                    cand |= 1u << gi;
+                    if (tn < near_tn) { near_tn = tn; near_g = gi; }
+                }
+            }
+            int best_g = -1;
+            auto exact = [&](int gi) {
+                const DevGeom& g = s_geoms[gi];
+                v3 tp, tnn;
+                float t = -1.0f;
+                if (g.type == AIPT_GEOM_CUBE) t = boxTest(g, o, d, tp, tnn);
+                else if (g.type == AIPT_GEOM_SPHERE) t = sphereTest(g, o, d, tp, tnn);
+                if (t > 0.0f && (t_min > t || (t_min == t && gi < best_g))) {
+                    t_min = t; materialid = g.materialid; hitP = tp; normal = tnn; best_g = gi;
+                }
+            };
+            if (near_g >= 0) { exact(near_g); cand &= ~(1u << near_g); }
             while (cand) {
                 const int gi = __builtin_ctz(cand);
                 cand &= cand - 1;
-                const DevGeom& g = s_geoms[gi];
-                v3 tp, tn;
-                float t = -1.0f;
-                if (g.type == AIPT_GEOM_CUBE) t = boxTest(g, o, d, tp, tn);
-                else if (g.type == AIPT_GEOM_SPHERE) t = sphereTest(g, o, d, tp, tn);
-                if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
+                float tn;
+                maybe_hits(s_geoms[gi].lo, s_geoms[gi].hi, o, inv, tn);
+                if (!(tn > t_min * 1.0001f + 1e-4f)) exact(gi);           // NaN -> test
             }
         } else {
             for (int gi = 0; gi < p.ngeoms; gi++) {
@@ -679,7 +735,8 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 if (t > 0.0f && t_min > t) { t_min = t; materialid = g.materialid; hitP = tp; normal = tn; }
             }
         }
-        if (MESH && !from_cache && p.nfaces && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
+        PHASE(1);
+        if (MESH && !from_cache && p.nfaces && !(p.flags & 0x40000000u) && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -706,6 +763,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 }
             }
         }
+        PHASE(2);
         const bool hit = materialid != -1;
         if (FIRST && p.cache_mode == 1) {                          // CACHE_BOUNCE, iter == 1 (:466-472)
             float* c = p.cache + i;
@@ -765,6 +823,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             alive_after = true;
         }
         p.alive[t] = alive_after ? 1 : 0;
+        PHASE(3);
     }
 
     // ---- live count of this workgroup for the next bounce
@@ -796,11 +855,12 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.bounce == 0 ? p.PT : p.n_live[p.bounce];
-    if ((int)(blockIdx.x * 256) >= n) return;
-    const int t = blockIdx.x * 256 + tid;
+    const int rpw = p.bounce == 0 ? 64 : rays_per_wave(p, n);     // the slot -> thread map of the bounce that just ran
+    if ((int)(blockIdx.x * 4 * rpw) >= n) return;
+    const int t = (blockIdx.x * 4 + wave) * rpw + lane;
     int i = 0;
     bool alive = false;
-    if (t < n) {
+    if (lane < rpw && t < n) {
         i = p.live_in ? p.live_in[t] : t;
         alive = p.alive[t] != 0;
     }
@@ -1122,7 +1182,7 @@ int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) 
     const size_t PT = (size_t)P * batch;
     const int nblk = (int)((PT + 255) / 256);
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_state, sizeof(float4) * 3 * PT));
-    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt, sizeof(int) * nblk));
+    AIPT_HIP(ctx, hipMalloc((void**)&s->d_cnt, sizeof(int) * (PT / 64 + 16)));       // a later bounce can run 64-path workgroups
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_alive, sizeof(int) * PT));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive_f, sizeof(int) * (MAX_DEPTH + 1) * BMAX));
@@ -1221,6 +1281,17 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     p.nframes = nframes; p.PT = nframes * s->P; p.PS = (size_t)s->P * s->batch; p.gbuf_frame = gbuf_frame;
     p.cams = s->d_cams; p.n_live_f = s->d_nlive_f;
     const int nblk = (p.PT + 255) / 256;
+    static const int rpw32 = getenv("AIPT_TRACE_RPW32_BELOW") ? atoi(getenv("AIPT_TRACE_RPW32_BELOW")) : 0;
+    static const int rpw16 = getenv("AIPT_TRACE_RPW16_BELOW") ? atoi(getenv("AIPT_TRACE_RPW16_BELOW")) : 0;
+    p.rpw32_below = rpw32; p.rpw16_below = rpw16 < rpw32 ? rpw16 : rpw32;
+    // workgroups a later bounce may need: its waves take 16 paths each only below rpw16_below live paths, 32 below rpw32_below
+    auto later_grid = [&](void) {
+        long need = nblk;
+        if (p.rpw32_below > 0) need = std::max<long>(need, (std::min<long>(p.PT, p.rpw32_below) + 127) / 128);
+        if (p.rpw16_below > 0) need = std::max<long>(need, (std::min<long>(p.PT, p.rpw16_below) + 63) / 64);
+        return (int)need;
+    };
+    const int nblk_late = later_grid();
     if (nframes > 1) {
         AIPT_HIP(ctx, hipMemcpyAsync(s->d_cams, cam, sizeof(aipt_camera) * nframes, hipMemcpyHostToDevice, st));
         AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive_f, 0, sizeof(int) * (MAX_DEPTH + 1) * BMAX, st));
@@ -1256,11 +1327,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
         if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
-        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
-        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);
+        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk_late), dim3(256), stack_bytes, st, p);
+        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk_late), dim3(256), lds_scene, st, p);
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[1], st));
         if (b + 1 < depth) {
-            hipLaunchKernelGGL(trace_compact, dim3(nblk), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(trace_compact, dim3(b == 0 ? nblk : nblk_late), dim3(256), 0, st, p);
             cur = nxt;
             if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)
                 const int srt = (cur + 1) % 3;
@@ -1333,7 +1404,9 @@ int aipt_debug_trace_stats(aipt_ctx* ctx, unsigned long long* out8, int reset) {
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
 #ifdef AIPT_TRACE_STATS
     if (out8) AIPT_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_trace_stats), 128));
-    if (reset) { unsigned long long z[16] = {0}; AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, 128)); }
+    if (out8 && reset == 2) AIPT_HIP(ctx, hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_phase), 64));     // reset == 2: the phase cycle sums instead
+    if (reset == 1) { unsigned long long z8[8] = {0}; AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z8, 64)); }
+    if (reset == 1) { unsigned long long z[16] = {0}; AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_trace_stats), z, 128)); }
     return AIPT_OK;
 #else
     (void)reset;

@@ -29,7 +29,7 @@ def main():
     out = (C.c_ulonglong * 16)()
     L = api.lib()
     prev = None
-    for d in range(1, depth + 1):              # depth d minus depth d-1 = bounce d-1 alone
+    for d in range(1, depth + 1 if not os.environ.get("PHASES_ONLY") else 1):              # depth d minus depth d-1 = bounce d-1 alone
         L.aipt_debug_trace_stats(ctx._h, out, 1)
         ctx.pathtrace(sc.camera, 1, d, g)
         ctx.sync()
@@ -45,6 +45,15 @@ def main():
         print(f"          rays that walked the BVH {int(delta[8:15].sum()):7d}; by node visits <=4,8,16,32,64,128,more: "
               f"{[int(v) for v in delta[8:15]]}; max so far {int(cur[5])}; max stack {int(cur[6])}, node visits with sp > 8: {int(delta[7])}, > 12: {int(delta[15])}")
         prev = cur
+    # phase cycle sums (one lane per wave): prologue, primitives, BVH walk + winner fetch, shade/scatter/store
+    ph = (C.c_ulonglong * 16)()
+    L.aipt_debug_trace_stats(ctx._h, ph, 1)
+    ctx.pathtrace(sc.camera, 1, depth, g)
+    ctx.sync()
+    L.aipt_debug_trace_stats(ctx._h, ph, 2)
+    v = np.array(list(ph)[:4], np.float64)
+    print("phase shares (cycles summed over waves, whole frame): prologue %.2f  primitives %.2f  walk %.2f  shade %.2f  (total %.3g cycles)"
+          % tuple(list(v / v.sum()) + [v.sum()]))
 
 
 if __name__ == "__main__":

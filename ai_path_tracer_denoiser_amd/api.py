@@ -84,6 +84,7 @@ ABI = [
     ("aipt_trace_live_counts_frame", C.c_int, [_P, C.c_int, _P, C.c_int]),
     ("aipt_frames_configure", C.c_int, [_P, C.c_int]),
     ("aipt_frames", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    ("aipt_frames_prefetch", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_uint32]),
     ("aipt_frames_gbuffer", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aipt_trace_profile_begin", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_trace_profile_end", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
@@ -434,6 +435,10 @@ class Context:
         f0 = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry_first else 0)
         f1 = (DN_BN_BATCH if bn_batch else 0) | (DN_HIDDEN_CARRY if carry else 0)
         self._ck(lib().aipt_frames(self._h, ca, len(cams), iter, depth, trace_flags, f0, f1, ptrs))
+
+    def frames_prefetch(self, cams, iter: int, depth: int, trace_flags: int = TRACE_DEFAULT):
+        ca = (Camera * len(cams))(*cams)
+        self._ck(lib().aipt_frames_prefetch(self._h, ca, len(cams), iter, depth, trace_flags))
 
     def frames_gbuffer(self, frame: int):
         p, r, s = _P(), C.c_int(), C.c_int()

@@ -80,8 +80,9 @@ void aipt_destroy(aipt_ctx* ctx) {
     aipt::trace_destroy(ctx);
     aipt::denoise_destroy(ctx);
     for (float* g : ctx->d_gbufs) if (g) hipFree(g);
-    if (ctx->d_gbatch) hipFree(ctx->d_gbatch);
+    for (float* g : ctx->d_gbatches) if (g) hipFree(g);
     for (auto& ev : ctx->bev) if (ev) hipEventDestroy(ev);
+    for (auto& ev : ctx->ev_bdenoised) if (ev) hipEventDestroy(ev);
     for (auto& ev : ctx->ev_denoised) if (ev) hipEventDestroy(ev);
     if (ctx->ev_prefetched) hipEventDestroy(ctx->ev_prefetched);
     if (ctx->ev_traced) hipEventDestroy(ctx->ev_traced);
@@ -161,6 +162,17 @@ int aipt_timer_stop(aipt_ctx* ctx, float* ms_out) {
 // ---------------------------------------------------------------------------------------------------- frame
 static inline int round_up32(int v) { return (v + 31) & ~31; }
 
+namespace aipt {
+// the prefetch stream runs at the lowest priority: its trace workgroups fill what the denoiser leaves idle instead of
+// delaying the convolutions of the frame being denoised (which are on the critical path of the sequence)
+hipError_t create_side_stream(aipt_ctx* ctx) {
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least);
+}
+}  // namespace aipt
+
 int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     AIPT_CHECK_CTX(ctx);
     if (width <= 0 || height <= 0) return fail(ctx, AIPT_E_INVALID, "aipt_frame_configure: %dx%d", width, height);
@@ -173,7 +185,8 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     if (rc) return rc;
     if (ctx->side) AIPT_HIP(ctx, hipStreamSynchronize(ctx->side));
     for (float*& g : ctx->d_gbufs) if (g) { hipFree(g); g = nullptr; }
-    if (ctx->d_gbatch) { hipFree(ctx->d_gbatch); ctx->d_gbatch = nullptr; }
+    for (float*& g : ctx->d_gbatches) if (g) { hipFree(g); g = nullptr; }
+    ctx->d_gbatch = nullptr; ctx->bpf.valid = false; ctx->bdenoised_valid[0] = ctx->bdenoised_valid[1] = false;
     ctx->fbatch = 1;
     ctx->d_gbuf = nullptr; ctx->front = 0; ctx->pf.valid = false;
     ctx->denoised_valid[0] = ctx->denoised_valid[1] = false;
@@ -250,12 +263,17 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch) {
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     const int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch);
     if (rc) return rc;
-    if (ctx->d_gbatch) { hipFree(ctx->d_gbatch); ctx->d_gbatch = nullptr; }
+    for (float*& g : ctx->d_gbatches) if (g) { hipFree(g); g = nullptr; }
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
-    AIPT_HIP(ctx, hipMalloc((void**)&ctx->d_gbatch, sizeof(float) * frame * batch));
-    AIPT_HIP(ctx, hipMemsetAsync(ctx->d_gbatch, 0, sizeof(float) * frame * batch, ctx->stream));   // padding = miss pixels = 0
+    for (float*& g : ctx->d_gbatches) {
+        AIPT_HIP(ctx, hipMalloc((void**)&g, sizeof(float) * frame * batch));
+        AIPT_HIP(ctx, hipMemsetAsync(g, 0, sizeof(float) * frame * batch, ctx->stream));   // padding = miss pixels = 0
+    }
     AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->bev[0]) for (auto& ev : ctx->bev) hipEventCreate(&ev);
+    if (!ctx->ev_bdenoised[0]) for (auto& ev : ctx->ev_bdenoised) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    ctx->bfront = 0; ctx->d_gbatch = ctx->d_gbatches[0];
+    ctx->bdenoised_valid[0] = ctx->bdenoised_valid[1] = false; ctx->bpf.valid = false;
     ctx->fbatch = batch;
     ctx->pf.valid = false;
     return AIPT_OK;
@@ -271,19 +289,50 @@ int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, i
     ctx->pf.valid = false;
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[0], ctx->stream));
-    int rc = aipt::trace_on_stream(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatch, ctx->fhp, ctx->fwp, frame);
-    if (rc) return rc;
+    int rc;
+    const bool hit = ctx->bpf.valid && ctx->bpf.iter == iter && ctx->bpf.depth == depth && ctx->bpf.flags == trace_flags &&
+                     (int)ctx->bpf.cams.size() == nframes && !memcmp(ctx->bpf.cams.data(), cams, sizeof(aipt_camera) * nframes);
+    ctx->bpf.valid = false;                                    // a mismatching prefetch is dropped
+    if (hit) {
+        ctx->bfront = ctx->bpf.buf;
+        AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prefetched, 0));
+    } else {
+        rc = aipt::trace_on_stream(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[ctx->bfront], ctx->fhp, ctx->fwp, frame);
+        if (rc) return rc;
+    }
+    ctx->d_gbatch = ctx->d_gbatches[ctx->bfront];
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
     for (int j = 0; j < nframes; j++) {
         rc = aipt::denoise_run(ctx, ctx->d_gbatch + j * frame, d_out3[j], j == 0 ? dn_flags_first : dn_flags_rest, ctx->fh, ctx->fw);
         if (rc) return rc;
     }
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_bdenoised[ctx->bfront], ctx->stream));
+    ctx->bdenoised_valid[ctx->bfront] = true;
     ctx->d_gbuf = ctx->d_gbatch + (size_t)(nframes - 1) * frame;
     ctx->last_batch = nframes;
     if (ctx->frame_timing) {
         AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
         ctx->frame_timed = true;
     }
+    return AIPT_OK;
+}
+
+int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags) {
+    AIPT_CHECK_CTX(ctx);
+    if (!ctx->d_gbatch) return fail(ctx, AIPT_E_STATE, "aipt_frames_prefetch: call aipt_frames_configure first");
+    if (!cams || nframes < 1 || nframes > ctx->fbatch) return fail(ctx, AIPT_E_INVALID, "aipt_frames_prefetch: %d frames, configured for %d", nframes, ctx->fbatch);
+    if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frames_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->side) AIPT_HIP(ctx, aipt::create_side_stream(ctx));
+    const int back = ctx->bfront ^ 1;
+    // the denoiser passes that last read the back G-buffers must be done before the trace overwrites them
+    if (ctx->bdenoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_bdenoised[back], 0));
+    const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
+    const int rc = aipt::trace_on_stream(ctx, ctx->side, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back], ctx->fhp, ctx->fwp, frame);
+    if (rc) return rc;
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
+    ctx->bpf.valid = true; ctx->bpf.cams.assign(cams, cams + nframes); ctx->bpf.iter = iter; ctx->bpf.depth = depth;
+    ctx->bpf.flags = trace_flags; ctx->bpf.buf = back;
     return AIPT_OK;
 }
 
@@ -307,7 +356,7 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     // later iteration traced into the OTHER buffer would be denoised with stale planes, so only iteration 1 can be prefetched
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->side) AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    if (!ctx->side) AIPT_HIP(ctx, aipt::create_side_stream(ctx));
     const int back = ctx->front ^ 1;
     // the denoise that last read the back G-buffer must be done before the trace overwrites it
     if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_denoised[back], 0));

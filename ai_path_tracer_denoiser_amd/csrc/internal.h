@@ -44,7 +44,12 @@ struct aipt_ctx {
     struct { bool valid = false; aipt_camera cam; int iter = 0, depth = 0; uint32_t flags = 0; int buf = 0; } pf;
     // aipt_frames: a batch of frames traced together, then denoised in order
     int fbatch = 1;
-    float* d_gbatch = nullptr;    // [fbatch][10][fhp][fwp]
+    float* d_gbatch = nullptr;    // [fbatch][10][fhp][fwp]: the G-buffers of the batch being denoised (= d_gbatches[bfront])
+    float* d_gbatches[2] = {nullptr, nullptr};   // double buffer: aipt_frames_prefetch traces the next batch into the back one
+    int bfront = 0;
+    hipEvent_t ev_bdenoised[2] = {nullptr, nullptr};   // the denoiser passes that read d_gbatches[i] have finished
+    bool bdenoised_valid[2] = {false, false};
+    struct { bool valid = false; std::vector<aipt_camera> cams; int iter = 0, depth = 0; uint32_t flags = 0; int buf = 0; } bpf;
     hipEvent_t bev[2] = {nullptr, nullptr};
     int last_batch = 1;
 };

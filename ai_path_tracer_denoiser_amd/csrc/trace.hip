@@ -87,8 +87,7 @@ struct TraceState {
 };
 
 struct TraceParams {
-    aipt_camera cam;             // the camera of a single-frame trace (kernel argument); batched: cams[frame] in HBM
-    const aipt_camera* cams;
+    aipt_camera cams[BMAX];      // cameras of the frames traced together (kernel argument; cams[0] for a single frame)
     int nframes;                 // frames traced together: path i = frame i / P, pixel i % P
     int PT;                      // nframes * P paths
     size_t PS;                   // plane stride of the per-path buffers (their capacity, batch * P)
@@ -649,8 +648,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         v3 o, d, col;
         if (FIRST) {                                                             // generateRayFromCamera :155-182
             const int x = pix % p.W, y = pix / p.W;
-            aipt_camera cam = p.cam;
-            if (p.nframes > 1) cam = p.cams[fr];
+            const aipt_camera& cam = p.cams[fr];
             const v3 view = V(cam.view[0], cam.view[1], cam.view[2]);
             const v3 right = V(cam.right[0], cam.right[1], cam.right[2]);
             const v3 up = V(cam.up[0], cam.up[1], cam.up[2]);
@@ -1276,10 +1274,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         }
     }
     TraceParams p;
-    p.cam = cam[0]; p.iter = iter; p.trace_depth = depth; p.flags = flags;
+    for (int f = 0; f < nframes; f++) p.cams[f] = cam[f];
+    p.iter = iter; p.trace_depth = depth; p.flags = flags;
     p.W = s->W; p.H = s->H; p.P = s->P;
     p.nframes = nframes; p.PT = nframes * s->P; p.PS = (size_t)s->P * s->batch; p.gbuf_frame = gbuf_frame;
-    p.cams = s->d_cams; p.n_live_f = s->d_nlive_f;
+    p.n_live_f = s->d_nlive_f;
     const int nblk = (p.PT + 255) / 256;
     static const int rpw32 = getenv("AIPT_TRACE_RPW32_BELOW") ? atoi(getenv("AIPT_TRACE_RPW32_BELOW")) : 0;
     static const int rpw16 = getenv("AIPT_TRACE_RPW16_BELOW") ? atoi(getenv("AIPT_TRACE_RPW16_BELOW")) : 0;
@@ -1292,10 +1291,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         return (int)need;
     };
     const int nblk_late = later_grid();
-    if (nframes > 1) {
-        AIPT_HIP(ctx, hipMemcpyAsync(s->d_cams, cam, sizeof(aipt_camera) * nframes, hipMemcpyHostToDevice, st));
-        AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive_f, 0, sizeof(int) * (MAX_DEPTH + 1) * BMAX, st));
-    }
+    if (nframes > 1) AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive_f, 0, sizeof(int) * (MAX_DEPTH + 1) * BMAX, st));
     p.st = s->d_state;
     p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats; p.nmats = s->nmats;
     p.faces = s->d_faces; p.nfaces = s->nfaces; p.box = s->box;

@@ -201,6 +201,9 @@ def main():
             if nb > 1:
                 ctx.frames(cams[k:k + nb], 1, depth, outs[:nb], trace_flags=trace_flags, bn_batch=bn_batch,
                            carry_first=carry and k > 0, carry=carry)
+                nn = min(B, k1 - (k + nb))
+                if args.prefetch and nn > 1:                  # next batch's trace on the side stream during these denoiser passes
+                    ctx.frames_prefetch(cams[k + nb:k + nb + nn], 1, depth, trace_flags)
             else:
                 ctx.frame(cams[k], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry and k > 0)
                 # pipelining: frame k+1 is traced on the side stream while frame k is denoised -- never across the

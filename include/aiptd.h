@@ -249,6 +249,9 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch);
 int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
                 uint32_t dn_flags_first, uint32_t dn_flags_rest, float* const* d_out3);
 int aipt_frames_gbuffer(aipt_ctx* ctx, int frame, float** d_gbuf, int* rows, int* stride);
+/* like aipt_frame_prefetch, for batches: traces the NEXT batch on the second stream into the back set of G-buffers while the
+ * current batch is denoised; the following aipt_frames with identical (cams, iter, depth, trace_flags) consumes it. */
+int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags);
 /* the context-owned padded G-buffer float[10][Hp][Wp] of the last aipt_frame (device pointer) and its padded size */
 int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);
 /* per-stage GPU time of the last aipt_frame with timing enabled (ms; synchronous) */

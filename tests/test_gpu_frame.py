@@ -173,7 +173,7 @@ def test_frame_batches_equal_the_frame_by_frame_sequence():
     cams = [sc.orbit(phi=sc.phi + 0.1 * k) for k in range(7)]
     blob = synth.make_blob(7)
 
-    def run(batch):
+    def run(batch, prefetch=False):
         ctx = api.Context(0)
         ctx.pathtrace_init(sc.geoms, mats, faces, box)
         ctx.load_weights(blob)
@@ -192,14 +192,16 @@ def test_frame_batches_equal_the_frame_by_frame_sequence():
             while k < len(cams):
                 nb = min(batch, len(cams) - k)
                 ctx.frames(cams[k:k + nb], 1, depth, ob, bn_batch=True, carry_first=k > 0, carry=True)
+                if prefetch and k + nb < len(cams):       # the next batch's trace overlaps these denoiser passes
+                    ctx.frames_prefetch(cams[k + nb:k + nb + min(batch, len(cams) - k - nb)], 1, depth)
                 ctx.sync()
                 outs += [ob[j].cpu().numpy().copy() for j in range(nb)]
                 k += nb
         ctx.close()
         return outs
     ref = run(1)
-    for batch in (3, 4):
-        got = run(batch)
+    for batch, pf in ((3, False), (4, False), (3, True)):
+        got = run(batch, pf)
         assert len(got) == len(ref)
         for k in range(len(ref)):
-            assert np.array_equal(got[k], ref[k]), (batch, k)
+            assert np.array_equal(got[k], ref[k]), (batch, pf, k)

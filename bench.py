@@ -13,6 +13,12 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     node has fewer GPUs); under torch.distributed.run: one rank per GPU, frames are sharded in contiguous chunks, rank 0
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
+Frame batches (results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): on mesh scenes the traces of 4
+consecutive frames share one set of bounce launches (a single 1280x720 frame leaves most of the chip idle in its later bounces:
+every launch lasts as long as its slowest wave's chain of dependent BVH fetches); the four denoiser passes follow in order with
+the hidden state carried.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is measured on
+one single frame after the timed region.
+
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the kernel that dominates THIS workload (HIP events on the
 launch stream inside the timed region; the runner-up kernel under "roofline_other"), "cpu_baseline" (the CPU oracle timed
 on the host cores, N=1 only), "frame" (ms split and the whole-frame HBM fraction).
@@ -59,10 +65,12 @@ def parse_args():
     ap.add_argument("--hidden", choices=["carry", "reset"], default="carry")
     ap.add_argument("--impl", choices=["f32", "f16x3", "f16w"],
                     help="conv arithmetic: f32-input MFMA (exact fp32 chain), split-fp16 MFMA (default), or split-fp16 activations x fp16 weights")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="trace this many consecutive frames in one set of launches (aipt_frames; identical results)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
+                         "1 = frame by frame, aipt_frame).  Default: 4 on mesh scenes, 1 without a mesh")
     ap.add_argument("--prefetch", action="store_true",
-                    help="trace frame k+1 on a second stream during denoise k (aipt_frame_prefetch)")
+                    help="also trace the next batch (frame) on a low-priority second stream during the denoiser passes of this "
+                         "one (+9 %% on configs[2], but the streams' kernels fight for CUs on the reflective scene: off by default)")
     ap.add_argument("--trace-flags", type=int, default=None, help="AIPT_TRACE_* bits (default AA | COMPACT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
@@ -77,6 +85,8 @@ def parse_args():
     args.mesh = ntri if args.mesh is None else args.mesh
     args.mesh_kind = args.mesh_kind or kind or "atrium"
     args.impl = args.impl or impl
+    if args.batch is None:
+        args.batch = 4 if args.mesh else 1
     return args
 
 
@@ -256,14 +266,7 @@ def main():
         ctx.trace_profile_begin(nrec, PROF_EVERY if B == 1 else 1)
     barrier()
     t0 = time.perf_counter()
-    if B == 1:
-        for k in range(args.warmup, per_rank):
-            if k == per_rank - 1:
-                ctx.frame_set_timing(True)                    # trace/denoise split of the last frame only
-            run_frames(k, k + 1)
-    else:
-        ctx.frame_set_timing(True)
-        run_frames(args.warmup, per_rank)
+    run_frames(args.warmup, per_rank)
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
@@ -272,8 +275,12 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    trace_ms, denoise_ms = ctx.frame_last_times()
     n_live = ctx.live_counts(depth)            # of the last trace call (all frames of the last batch together)
+    # the trace / denoise split: one un-pipelined frame, after the timed region
+    ctx.sync()
+    ctx.frame_set_timing(True)
+    ctx.frame(cams[per_rank - 1], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry)
+    trace_ms, denoise_ms = ctx.frame_last_times()
     P = W * H
     Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
 
@@ -377,12 +384,14 @@ def main():
                                    f"BN {args.bn}-stats, hidden {args.hidden}, conv {args.impl}",
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
-                       "pipelining": (f"traces of {B} consecutive frames share their launches (aipt_frames)" if B > 1 else
-                                      "trace(k+1) on a side stream during denoise(k)" if args.prefetch else "none")},
+                       "pipelining": ((f"traces of {B} consecutive frames share their launches (aipt_frames)" if B > 1 else "frame by frame")
+                                      + ("; the next batch is traced on a second stream during the denoiser passes" if args.prefetch else "")
+                                      + "; frames bit-identical to un-pipelined rendering")},
             "roofline": roof,
             "roofline_other": other,
             "cpu_baseline": cpu,
-            "frame": {"ms_trace_last": round(trace_ms, 4), "ms_denoise_last": round(denoise_ms, 4),
+            "frame": {"ms_trace": round(trace_ms, 4), "ms_denoise": round(denoise_ms, 4),
+                      "split_note": "one un-pipelined frame (aipt_frame) after the timed region",
                       "algorithmic_bytes": trace_bytes + dn_bytes, "denoise_gflop": arch.conv_flops(Hp, Wp) / 1e9,
                       "hbm_frac_of_8TBps": round((trace_bytes + dn_bytes) / (ms_per_step * 1e-3) / MI355X_HBM_BPS, 5),
                       "n_live": [int(v) // last_frames for v in n_live], "n_live_note": "per frame (mean over the last batch)" if last_frames > 1 else "last frame"},

@@ -1,50 +1,64 @@
 #!/usr/bin/env python3
 """Summarise the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of bench.py into profiles/pmc_dominant.json.
 
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline-events
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o p -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline-events
-    python tools/pmc_summarize.py gpurun_out/pmc_f/p_counter_collection.csv gpurun_out/pmc_w/p_counter_collection.csv 'conv3x3_f16x3<1,8,false>'
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline-events
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-roofline-events
+    python tools/pmc_summarize.py gpurun_out/pmc_fetch/p_counter_collection.csv gpurun_out/pmc_write/p_counter_collection.csv \\
+        'trace_bounce<false,true>' 'conv3x3_f16x3<1,8,false,false>' ...
 
-Units and corrections as MI355X_MICROARCH.md prescribes: both counters are in KiB; FETCH_SIZE is doubled on gfx950 (wide
-coalesced reads are reported at half); separate passes because the two counters do not share a pass reliably."""
+(the SAME bench.py command line the roofline block is measured with, so "per launch" means the same launch: with the default
+--batch 4 a bounce launch covers four frames).  Units and corrections as MI355X_MICROARCH.md prescribes: both counters are in
+KiB; FETCH_SIZE is doubled on gfx950 (wide coalesced reads are reported at half); separate passes because the two counters do
+not share a pass.  bench.py reads {"kernels": {name: {"hbm_bytes_per_launch": ...}}} for roofline.traffic."""
 import csv
 import json
 import os
 import sys
 
 
-def per_launch(path, counter, kernel):
-    vals = []
+def short(name):
+    n = name.replace("void aipt::", "").replace("aipt::", "")
+    depth = 0
+    for i, ch in enumerate(n):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            n = n[:i]
+            break
+    return n.replace(" ", "")
+
+
+def per_launch(path, counter):
+    acc = {}
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].replace("void aipt::", "").split("(")[0].replace(" ", "")
-        if name == kernel and r["Counter_Name"] == counter:
-            vals.append(float(r["Counter_Value"]))
-    if not vals:
-        raise SystemExit(f"{path}: no {counter} rows for kernel {kernel}")
-    return sum(vals) / len(vals), len(vals)
+        if r["Counter_Name"] == counter:
+            acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+    return acc
 
 
 def main():
-    fcsv, wcsv, kernel = sys.argv[1:4]
-    f, nf = per_launch(fcsv, "FETCH_SIZE", kernel)
-    w, nw = per_launch(wcsv, "WRITE_SIZE", kernel)
-    fetch = 2.0 * f * 1024.0
-    write = w * 1024.0
-    out = {
-        "kernel": kernel,
-        "hbm_bytes_per_launch": fetch + write,
-        "fetch_bytes_per_launch": fetch,
-        "write_bytes_per_launch": write,
-        "launches_averaged": [nf, nw],
-        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 3 --warmup 2 "
-                  "--no-cpu-baseline --no-roofline-events); KiB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md "
-                  "(gfx950 reports half of wide coalesced reads); WRITE_SIZE uncalibrated; averaged over all launches "
-                  "of the kernel in the run (tools/pmc_summarize.py)",
-    }
+    fcsv, wcsv = sys.argv[1:3]
+    kernels = sys.argv[3:]
+    f, w = per_launch(fcsv, "FETCH_SIZE"), per_launch(wcsv, "WRITE_SIZE")
+    out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the default bench.py command "
+                     "(--steps 8 --warmup 4 --no-cpu-baseline --no-roofline-events); KiB -> bytes; FETCH_SIZE doubled per "
+                     "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; the BVH walk's 16-byte gathers are not "
+                     "the calibrated pattern, so its figure is an upper bound); WRITE_SIZE uncalibrated; averaged over all "
+                     "launches of the kernel in the run (tools/pmc_summarize.py)",
+           "kernels": {}}
+    for k in kernels:
+        if k not in f or k not in w:
+            raise SystemExit(f"no rows for kernel {k}; have {sorted(f)}")
+        fetch = 2.0 * 1024.0 * sum(f[k]) / len(f[k])
+        write = 1024.0 * sum(w[k]) / len(w[k])
+        out["kernels"][k] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch,
+                             "write_bytes_per_launch": write, "launches_averaged": [len(f[k]), len(w[k])]}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "pmc_dominant.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps(out))
+    print(json.dumps(out["kernels"]))
 
 
 if __name__ == "__main__":

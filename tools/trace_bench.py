@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--sizes", default="1280x720,2560x1440")
     ap.add_argument("--flags", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1)
     args = ap.parse_args()
     import torch
     from ai_path_tracer_denoiser_amd import api, synth
@@ -41,20 +42,29 @@ def main():
             faces, lb, ub = synth.make_atrium_mesh(args.mesh, 565, material=first, floor_material=refl, column_material=refl)
         box = api.AABB(); box.lb[:] = [float(v) for v in lb]; box.ub[:] = [float(v) for v in ub]
         ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
-        g = torch.zeros(10, H, W, device="cuda")
+        B = args.batch
+        if B > 1:
+            ctx.trace_configure_batch(W, H, B)
+        g = torch.zeros(B, 10, H, W, device="cuda")
         torch.cuda.synchronize()
-        cams = [sc.orbit(phi=adist.pan_phi(sc.phi, k)) for k in range(args.frames + 2)]
+        cams = [sc.orbit(phi=adist.pan_phi(sc.phi, k)) for k in range((args.frames + 2) * B)]
+
+        def trace(k):
+            if B > 1:
+                ctx.pathtrace_batch(cams[k * B:(k + 1) * B], 1, args.depth, g, args.flags)
+            else:
+                ctx.pathtrace(cams[k], 1, args.depth, g[0], args.flags)
         for k in range(2):
-            ctx.pathtrace(cams[k], 1, args.depth, g, args.flags)
+            trace(k)
         ctx.sync()
         ctx.trace_profile_begin(args.frames, 1)
         ctx.timer_start()
         for k in range(args.frames):
-            ctx.pathtrace(cams[2 + k], 1, args.depth, g, args.flags)
-        ms = ctx.timer_stop() / args.frames
+            trace(2 + k)
+        ms = ctx.timer_stop() / args.frames / B
         per, calls = ctx.trace_profile_end(args.depth)
-        n = ctx.live_counts(args.depth)
-        print(f"{size} {args.kind} {args.mesh} tris depth {args.depth}: trace {ms:.3f} ms/frame; bounce launches (us): "
+        n = ctx.live_counts(args.depth) // B
+        print(f"{size} {args.kind} {args.mesh} tris depth {args.depth} batch {B}: trace {ms:.3f} ms/frame; bounce launches (us): "
               f"{[round(1e3 * v / max(1, calls), 1) for v in per]}; rays {int(n[:-1].sum())} -> {n[:-1].sum() / ms / 1e6:.2f} Grays/s")
     ctx.close()
 

@@ -7,7 +7,7 @@
 // Data layout in HBM: every activation is fp32 in the channel-quad interleaved "C4" layout [C/4][h][w][4] (see ConvSrc);
 // the planar G-buffer input is read as it is by the first conv.
 // Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and
-// adds its per-channel sum / sum of squares to the layer's statistics table (fp64 atomics, 8 replicas); the CONSUMER turns
+// adds its per-channel sum / sum of squares to the layer's statistics table (64-bit fixed-point atomics, 8 replicas); the CONSUMER turns
 // them into the per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a) in its prologue (BnRef / bn_ab) and
 // applies x -> lrelu(a*x+b) while it stages its input tile into LDS, so BatchNorm, LeakyReLU, channel concat (two source
 // pointers) and nearest upsample (source indexed at (y>>1, x>>1)) never touch HBM as separate passes and there is no
@@ -42,12 +42,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // loads from planar tensors, tools/membench.hip).  Pad channels of the last quad hold 0.  Only the network input (the
 // G-buffer contract is planar, pathtrace.cu:81-94) and the API-facing outputs are planar.
 // How a consumer obtains the per-channel affine (a, b) of a tensor (y = lrelu(a*x + b)).  Batch-statistics BatchNorm: the
-// producing conv left per-channel sums in `stat` (fp64 atomics into NSLOT replicas, slot = workgroup % NSLOT: 3680
+// producing conv left per-channel sums in `stat` (64-bit atomics into NSLOT replicas, slot = workgroup % NSLOT: 3680
 // workgroups x 64 atomics cost 1.6 us that way, tools/atomicbench.hip) and every consumer workgroup turns them into
 // (a, b) itself in its prologue -- there is no finalize launch between two convs (28 launches x 4.1 us per frame).
-// fp64 sums of fp32 partials are exact for any realistic spread of magnitudes, so the result does not depend on the order
-// of the atomics.  Running statistics / identity: `ab` (or nothing).
+// The sums are 64-bit FIXED-POINT integers (24 fractional bits, |sum| < 2^39 = 5.5e11: a mean square below 5.8e5 at 1280x736;
+// raw conv outputs of a BatchNorm network are O(10)): integer addition is associative, so the statistics -- and with them
+// every output bit -- do not depend on the order in which the workgroups' atomics land.  (fp64 sums of fp32 partials are
+// exact only while all partials fit one 53-bit window; a channel with a wide spread of partial magnitudes broke
+// run-to-run equality about once in 15 runs.)  A partial is rounded to 2^-24 once (6e-8 absolute on a workgroup's sum
+// over >= 128 pixels), far below BatchNorm's eps.  The table stays addressed as doubles (8-byte slots).
+// Running statistics / identity: `ab` (or nothing).
 constexpr int NSLOT = 8;
+constexpr double BN_FIX = 16777216.0, BN_FIX_INV = 1.0 / 16777216.0;       // 2^24
 struct BnRef {
     const float2* ab;      // explicit affine; with stat == nullptr and ab == nullptr: identity
     const double* stat;    // [NSLOT][sc][2]: sum, sum of squares
@@ -60,14 +66,15 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
     if (r.stat) {
         // all replicas are loaded before the first add: written as one accumulate loop, hipcc waits for each 16-byte load
         // before issuing the next (8 serial L2 round trips, 7 k cycles per consumer workgroup)
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2* st = reinterpret_cast<const d2*>(r.stat) + c;
-        d2 v[NSLOT];
+        typedef long long l2 __attribute__((ext_vector_type(2)));
+        const l2* st = reinterpret_cast<const l2*>(r.stat) + c;
+        l2 v[NSLOT];
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) v[k] = __builtin_nontemporal_load(st + (size_t)k * r.sc);
-        double sx = 0.0, sxx = 0.0;
+        long long ix = 0, ixx = 0;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) { sx += v[k][0]; sxx += v[k][1]; }
+        for (int k = 0; k < NSLOT; k++) { ix += v[k][0]; ixx += v[k][1]; }
+        const double sx = (double)ix * BN_FIX_INV, sxx = (double)ixx * BN_FIX_INV;
         const double mean = sx * r.inv_n;
         double var = sxx * r.inv_n - mean * mean;          // biased variance, as torch normalises with
         if (var < 0) var = 0;
@@ -78,10 +85,17 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
     return r.ab ? r.ab[c] : make_float2(1.0f, 0.0f);
 }
 // a workgroup's BN sums of channel c (already reduced over the workgroup) -> the producer's stat table
+__device__ __forceinline__ long long bn_fix(double v) {      // fixed point, 24 fractional bits; clamped so that NaN / inf stay defined
+    v = fmin(fmax(v * BN_FIX, -4.0e18), 4.0e18);
+    return v == v ? __double2ll_rn(v) : 0ll;
+}
+__device__ __forceinline__ void bn_accumulate_slot(double* stat, int sc, int slot, int c, double sum, double sumsq) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(stat + ((size_t)slot * sc + c) * 2);
+    atomicAdd(a, (unsigned long long)bn_fix(sum));
+    atomicAdd(a + 1, (unsigned long long)bn_fix(sumsq));
+}
 __device__ __forceinline__ void bn_accumulate(double* stat, int sc, int c, float sum, float sumsq) {
-    double* a = stat + ((size_t)(blockIdx.x % NSLOT) * sc + c) * 2;
-    atomicAdd(a, (double)sum);
-    atomicAdd(a + 1, (double)sumsq);
+    bn_accumulate_slot(stat, sc, blockIdx.x % NSLOT, c, (double)sum, (double)sumsq);
 }
 
 struct ConvSrc {
@@ -531,7 +545,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         tab_a[kc] = t.x;
         tab_b[kc] = t.y;
     }
-    for (int i = tid; i < 2 * Cfg::A_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    // zeroed halo image: only tiles whose halo leaves the image need it (out-of-image units never write); an interior tile
+    // overwrites every byte the MFMA phase reads, every chunk
+    const bool halo_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + 33 <= W;
+    if (!halo_inside)
+        for (int i = tid; i < 2 * Cfg::A_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
 
     // chunk-invariant staging units: this thread stages channel quad q of halo pixels slot, slot+TPQ, ...
     const int q = tid / TPQ, slot = tid - q * TPQ;
@@ -818,9 +836,7 @@ __global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
         if (tid < COUT && tid < g.cout) {
             float2 t = red[0][tid];
             for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
-            double* st = g.stat + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) % NSLOT) * g.sc + tid) * 2;
-            atomicAdd(st, (double)t.x);
-            atomicAdd(st + 1, (double)t.y);
+            bn_accumulate_slot(g.stat, g.sc, (blockIdx.y * gridDim.x + blockIdx.x) % NSLOT, tid, (double)t.x, (double)t.y);
         }
     }
 }
@@ -949,7 +965,10 @@ __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, 
         if (threadIdx.x < s) { sa[threadIdx.x] += sa[threadIdx.x + s]; sb[threadIdx.x] += sb[threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { stat[blockIdx.x * 2] = sa[0]; stat[blockIdx.x * 2 + 1] = sb[0]; }   // slot 0 of a zeroed table
+    if (threadIdx.x == 0) {                                    // slot 0 of a zeroed table, in the table's fixed-point format
+        reinterpret_cast<long long*>(stat)[blockIdx.x * 2] = bn_fix(sa[0]);
+        reinterpret_cast<long long*>(stat)[blockIdx.x * 2 + 1] = bn_fix(sb[0]);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- elementwise

@@ -63,6 +63,8 @@ struct TraceState {
     int batch = 1;                // frames the per-path buffers below can hold (aipt_trace_configure_batch): sized batch * P
     aipt_camera* d_cams = nullptr;   // [BMAX] cameras of a batched trace
     int* d_nlive_f = nullptr;     // [MAX_DEPTH+1][BMAX] live paths per bounce and frame
+    int* d_cntf = nullptr;        // [workgroups][BMAX] per-frame survivor counts of the last bounce
+    int* d_rank[2] = {nullptr, nullptr};   // per-frame ranks of the live list entries (batched traces), ping-pong like d_live
     int last_frames = 1;
     float4* d_state = nullptr;    // [3][P]: (ox oy oz dx) (dy dz cr cg) (cb rem . .)
     int* d_cnt = nullptr;         // per-workgroup live counts of the last bounce
@@ -118,16 +120,11 @@ struct TraceParams {
     int* hist; int nkeys, nblk;
     const int* sort_in; int* sort_out;
     int* stack_ovf;                 // [stack bound - STACK_LDS][P] traversal-stack overflow (see WalkStack)
-    int rpw32_below, rpw16_below;   // rays_per_wave thresholds
+    // batched trace: per-frame survivor counts of every workgroup (bounce -> compact) and the per-frame rank of every live
+    // list entry (compact -> next bounce)
+    int* cntf;                      // [workgroups][BMAX]
+    const int* rank_in; int* rank_out;
 };
-
-// Rays per wave of a later bounce.  A wave runs the UNION of its lanes' walks (tools/trace_stats.py: ~50 node steps per wave for
-// ~7 per ray), and a launch lasts as long as its slowest wave; when a bounce has too few live paths to fill the chip anyway,
-// its waves take 32 or 16 paths each instead of 64: shorter unions, more waves, same total work.  A pure function of the live
-// count, so the bounce kernel and trace_compact agree on the slot -> thread map without talking to the host.
-__device__ __forceinline__ int rays_per_wave(const TraceParams& p, int n) {
-    return n < p.rpw16_below ? 16 : (n < p.rpw32_below ? 32 : 64);
-}
 
 // ---------------------------------------------------------------------------------------------- vector helpers
 __device__ __forceinline__ v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -601,32 +598,32 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     // every wave is full of live paths and the state planes are gathered/scattered through the pixel index.
     int i, idx, rem = 0;
     bool alive;
-    int t = blockIdx.x * 256 + tid;
+    const int t = blockIdx.x * 256 + tid;
     if (FIRST) {
         i = t; idx = t; alive = t < p.PT; rem = p.trace_depth;
     } else {
         const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
-        const int rpw = rays_per_wave(p, n);
-        if ((int)(blockIdx.x * 4 * rpw) >= n) {        // whole workgroup beyond the list
+        if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
             if (tid == 0) p.cnt[blockIdx.x] = 0;
+            if (p.nframes > 1 && tid < p.nframes) p.cntf[blockIdx.x * BMAX + tid] = 0;
             return;
         }
-        t = (blockIdx.x * 4 + wave) * rpw + lane;
-        alive = lane < rpw && t < n;
+        alive = t < n;
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
     }
-    // batched trace: frame and pixel of the path; the RNG index counts inside the frame
+    // Batched trace: the frames are INTERLEAVED pixel by pixel -- path i = pixel * nframes + frame -- so that neighbouring
+    // lanes hold the same pixel of consecutive frames.  The reference seeds its RNG with (iteration, index, depth) only
+    // (the same numbers every frame), so under a slow camera pan those paths are near copies of each other: they
+    // walk the same BVH nodes, and a wave's union of walks covers 64 / nframes distinct paths instead of 64.  The RNG index of
+    // a path is its rank among the live paths of ITS frame (what an unbatched trace of that frame computes): bounce 0 the
+    // pixel, later the per-frame rank trace_compact stored next to the live list.
     int fr = 0, pix = i;
     if (p.nframes > 1) {
-        fr = i / P;
-        pix = i - fr * P;
+        pix = i / p.nframes;
+        fr = i - pix * p.nframes;
         if (FIRST || !(p.flags & AIPT_TRACE_COMPACT)) idx = pix;
-        else {
-            int foff = 0;
-            for (int k = 0; k < p.nframes - 1; k++) foff += k < fr ? p.n_live_f[p.bounce * BMAX + k] : 0;
-            idx = t - foff;
-        }
+        else idx = alive ? p.rank_in[t] : 0;
     }
 
     // primitives and materials into LDS: the candidate loop and the shader index them per lane
@@ -800,7 +797,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             gb[p.plane * 7] = hit ? col.x : 0.0f;
             gb[p.plane * 8] = hit ? col.y : 0.0f;
             gb[p.plane * 9] = hit ? col.z : 0.0f;
-            if (p.mat0) p.mat0[i] = materialid;
+            if (p.mat0) p.mat0[(size_t)fr * P + pix] = materialid;
         }
         if (new_rem == 0) {
             // finalGather + copy_data (:393-402, :81-94): image += colour; planes 0-2 = image / iter.  At iter 1 the image
@@ -833,15 +830,48 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         p.cnt[blockIdx.x] = c;
         if (c) atomicAdd(&p.n_live[p.bounce + 1], c);
     }
-    if (p.nframes > 1) {                            // survivors per frame (a wave can straddle frames)
-        unsigned long long left = m2;
-        while (left) {
-            const int l = __ffsll((long long)left) - 1;
-            const int ff = __shfl(fr, l);
-            const unsigned long long same = __ballot(alive_after && fr == ff);
-            if (lane == l) atomicAdd(&p.n_live_f[(p.bounce + 1) * BMAX + ff], __popcll(same));
-            left &= ~same;
+    if (p.nframes > 1) {                            // survivors per frame: this workgroup's counts (for the per-frame ranks) and the totals
+        __shared__ int s_cf[BMAX];
+        if (tid < BMAX) s_cf[tid] = 0;
+        __syncthreads();
+        for (int f = 0; f < p.nframes; f++) {
+            const int c = __popcll(__ballot(alive_after && fr == f));
+            if (lane == 0 && c) atomicAdd(&s_cf[f], c);
         }
+        __syncthreads();
+        if (tid < p.nframes) {
+            p.cntf[blockIdx.x * BMAX + tid] = s_cf[tid];
+            if (s_cf[tid]) atomicAdd(&p.n_live_f[(p.bounce + 1) * BMAX + tid], s_cf[tid]);
+        }
+    }
+}
+
+// Batched traces: exclusive prefix over the workgroups of the survivor counts (all frames, and every frame on its own), in
+// place, by one workgroup -- trace_compact then finds its bases with one load each instead of summing all lower workgroups
+// (with nframes x more workgroups and nframes + 1 counters that sum would grow quadratically).
+__global__ __launch_bounds__(1024) void trace_scan(const TraceParams p) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int n = p.bounce == 0 ? p.PT : p.n_live[p.bounce];
+    const int nb = (n + 255) / 256;                            // workgroups of the bounce that hold paths
+    const int per = (nb + 1023) / 1024;
+    const int lo = tid * per, hi = min(nb, lo + per);
+    for (int f = -1; f < p.nframes; f++) {                     // f = -1: all frames together (cnt), then frame f (cntf)
+        int* a = f < 0 ? p.cnt : p.cntf + f;
+        const int stride = f < 0 ? 1 : BMAX;
+        int sum = 0;
+        for (int k = lo; k < hi; k++) sum += a[k * stride];
+        __syncthreads();
+        s_part[tid] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int v = tid >= o ? s_part[tid - o] : 0;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        int run = s_part[tid] - sum;
+        for (int k = lo; k < hi; k++) { const int c = a[k * stride]; a[k * stride] = run; run += c; }
     }
 }
 
@@ -853,18 +883,20 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     __shared__ int s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.bounce == 0 ? p.PT : p.n_live[p.bounce];
-    const int rpw = p.bounce == 0 ? 64 : rays_per_wave(p, n);     // the slot -> thread map of the bounce that just ran
-    if ((int)(blockIdx.x * 4 * rpw) >= n) return;
-    const int t = (blockIdx.x * 4 + wave) * rpw + lane;
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int t = blockIdx.x * 256 + tid;
     int i = 0;
     bool alive = false;
-    if (lane < rpw && t < n) {
+    if (t < n) {
         i = p.live_in ? p.live_in[t] : t;
         alive = p.alive[t] != 0;
     }
     int part = 0;
-    for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt[j];
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (p.nframes > 1) part = lane == 0 && wave == 0 ? p.cnt[blockIdx.x] : 0;      // batched: trace_scan left the exclusive prefix
+    else {
+        for (int j = tid; j < (int)blockIdx.x; j += 256) part += p.cnt[j];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    }
     const unsigned long long mask = __ballot(alive);
     if (lane == 0) s_wave[wave] = part;
     __syncthreads();
@@ -876,7 +908,26 @@ __global__ __launch_bounds__(256) void trace_compact(const TraceParams p) {
     __syncthreads();
     int woff = 0;
     for (int w = 0; w < wave; w++) woff += s_wave[w];
-    if (alive) p.live_out[base + woff + __popcll(mask & ((1ull << lane) - 1ull))] = i;
+    const int slot = base + woff + __popcll(mask & ((1ull << lane) - 1ull));
+    if (alive) p.live_out[slot] = i;
+    if (p.nframes > 1) {
+        // per-frame rank of every survivor = survivors of ITS frame in lower workgroups + in lower waves + in lower lanes
+        __shared__ int s_fbase[BMAX], s_fw[4][BMAX];
+        const int fr = i % p.nframes;
+        if (tid < BMAX) s_fbase[tid] = tid < p.nframes ? p.cntf[blockIdx.x * BMAX + tid] : 0;   // exclusive prefix (trace_scan)
+        int my_rank = 0;
+        for (int f = 0; f < p.nframes; f++) {
+            const unsigned long long mf = __ballot(alive && fr == f);
+            if (lane == 0) s_fw[wave][f] = __popcll(mf);
+            if (fr == f) my_rank = __popcll(mf & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (alive) {
+            int r = s_fbase[fr] + my_rank;
+            for (int w = 0; w < wave; w++) r += s_fw[w][fr];
+            p.rank_out[slot] = r;
+        }
+    }
 }
 
 // ---- AIPT_TRACE_SORT_MATERIAL: stable counting sort of the compacted live list by material id ------------------------------
@@ -945,8 +996,8 @@ static void free_frame(TraceState* s) {
     hipFree(s->d_state); hipFree(s->d_cnt); hipFree(s->d_alive); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
     for (int*& l : s->d_live) { hipFree(l); l = nullptr; }
     hipFree(s->d_cache); hipFree(s->d_sortkey); hipFree(s->d_hist); hipFree(s->d_stack_ovf);
-    hipFree(s->d_cams); hipFree(s->d_nlive_f);
-    s->d_cams = nullptr; s->d_nlive_f = nullptr;
+    hipFree(s->d_cams); hipFree(s->d_nlive_f); hipFree(s->d_cntf); hipFree(s->d_rank[0]); hipFree(s->d_rank[1]);
+    s->d_cams = nullptr; s->d_nlive_f = nullptr; s->d_cntf = nullptr; s->d_rank[0] = s->d_rank[1] = nullptr;
     s->d_stack_ovf = nullptr; s->ovf_entries = 0;
     s->d_state = nullptr; s->d_cnt = nullptr; s->d_alive = nullptr; s->d_nlive = nullptr; s->d_mat0 = nullptr; s->d_image = nullptr;
     s->d_cache = nullptr; s->d_sortkey = nullptr; s->d_hist = nullptr; s->hist_keys = 0; s->cache_valid = false;
@@ -1185,6 +1236,11 @@ int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) 
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive, sizeof(int) * (MAX_DEPTH + 1)));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_nlive_f, sizeof(int) * (MAX_DEPTH + 1) * BMAX));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_cams, sizeof(aipt_camera) * BMAX));
+    if (batch > 1) {
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_cntf, sizeof(int) * (size_t)nblk * BMAX));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_rank[0], sizeof(int) * PT));
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_rank[1], sizeof(int) * PT));
+    }
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_mat0, sizeof(int) * PT));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_image, sizeof(float) * 3 * PT));
     AIPT_HIP(ctx, hipMalloc((void**)&s->d_live[0], sizeof(int) * PT));
@@ -1280,17 +1336,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     p.nframes = nframes; p.PT = nframes * s->P; p.PS = (size_t)s->P * s->batch; p.gbuf_frame = gbuf_frame;
     p.n_live_f = s->d_nlive_f;
     const int nblk = (p.PT + 255) / 256;
-    static const int rpw32 = getenv("AIPT_TRACE_RPW32_BELOW") ? atoi(getenv("AIPT_TRACE_RPW32_BELOW")) : 0;
-    static const int rpw16 = getenv("AIPT_TRACE_RPW16_BELOW") ? atoi(getenv("AIPT_TRACE_RPW16_BELOW")) : 0;
-    p.rpw32_below = rpw32; p.rpw16_below = rpw16 < rpw32 ? rpw16 : rpw32;
-    // workgroups a later bounce may need: its waves take 16 paths each only below rpw16_below live paths, 32 below rpw32_below
-    auto later_grid = [&](void) {
-        long need = nblk;
-        if (p.rpw32_below > 0) need = std::max<long>(need, (std::min<long>(p.PT, p.rpw32_below) + 127) / 128);
-        if (p.rpw16_below > 0) need = std::max<long>(need, (std::min<long>(p.PT, p.rpw16_below) + 63) / 64);
-        return (int)need;
-    };
-    const int nblk_late = later_grid();
+    p.cntf = s->d_cntf; p.rank_in = nullptr; p.rank_out = nullptr;
     if (nframes > 1) AIPT_HIP(ctx, hipMemsetAsync(s->d_nlive_f, 0, sizeof(int) * (MAX_DEPTH + 1) * BMAX, st));
     p.st = s->d_state;
     p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats; p.nmats = s->nmats;
@@ -1319,15 +1365,17 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         p.live_in = cur < 0 ? nullptr : s->d_live[cur];
         const int nxt = cur < 0 ? 0 : (cur + 1) % (sortmat ? 3 : 2);
         p.live_out = s->d_live[nxt];
+        if (nframes > 1) { p.rank_in = cur < 0 ? nullptr : s->d_rank[cur]; p.rank_out = s->d_rank[nxt]; }
         hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
         if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
-        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk_late), dim3(256), stack_bytes, st, p);
-        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk_late), dim3(256), lds_scene, st, p);
+        else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
+        else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[1], st));
         if (b + 1 < depth) {
-            hipLaunchKernelGGL(trace_compact, dim3(b == 0 ? nblk : nblk_late), dim3(256), 0, st, p);
+            if (nframes > 1) hipLaunchKernelGGL(trace_scan, dim3(1), dim3(1024), 0, st, p);
+            hipLaunchKernelGGL(trace_compact, dim3(nblk), dim3(256), 0, st, p);
             cur = nxt;
             if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)
                 const int srt = (cur + 1) % 3;

@@ -13,10 +13,10 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     node has fewer GPUs); under torch.distributed.run: one rank per GPU, frames are sharded in contiguous chunks, rank 0
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
-Frame batches (results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): on mesh scenes the traces of 4
+Frame batches (results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): on mesh scenes the traces of 8
 consecutive frames share one set of bounce launches (a single 1280x720 frame leaves most of the chip idle in its later bounces:
-every launch lasts as long as its slowest wave's chain of dependent BVH fetches); the four denoiser passes follow in order with
-the hidden state carried.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is measured on
+every launch lasts as long as its slowest wave's chain of dependent BVH fetches; the frames are interleaved pixel by pixel,
+so neighbouring lanes walk near-identical paths); the eight denoiser passes follow in order with the hidden state carried.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is measured on
 one single frame after the timed region.
 
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the kernel that dominates THIS workload (HIP events on the
@@ -67,7 +67,7 @@ def parse_args():
                     help="conv arithmetic: f32-input MFMA (exact fp32 chain), split-fp16 MFMA (default), or split-fp16 activations x fp16 weights")
     ap.add_argument("--batch", type=int, default=None,
                     help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
-                         "1 = frame by frame, aipt_frame).  Default: 4 on mesh scenes, 1 without a mesh")
+                         "1 = frame by frame, aipt_frame).  Default: 8 on mesh scenes, 1 without a mesh")
     ap.add_argument("--prefetch", action="store_true",
                     help="also trace the next batch (frame) on a low-priority second stream during the denoiser passes of this "
                          "one (+9 %% on configs[2], but the streams' kernels fight for CUs on the reflective scene: off by default)")
@@ -86,7 +86,7 @@ def parse_args():
     args.mesh_kind = args.mesh_kind or kind or "atrium"
     args.impl = args.impl or impl
     if args.batch is None:
-        args.batch = 4 if args.mesh else 1
+        args.batch = 8 if args.mesh else 1
     return args
 
 

@@ -846,32 +846,33 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     }
 }
 
-// Batched traces: exclusive prefix over the workgroups of the survivor counts (all frames, and every frame on its own), in
-// place, by one workgroup -- trace_compact then finds its bases with one load each instead of summing all lower workgroups
-// (with nframes x more workgroups and nframes + 1 counters that sum would grow quadratically).
+// Batched traces: exclusive prefix over the workgroups of the survivor counts, in place -- blockIdx 0: all frames together
+// (cnt), blockIdx 1 + f: frame f on its own (cntf) -- so that trace_compact finds its bases with one load each instead of
+// summing all lower workgroups (with nframes x more workgroups and nframes + 1 counters that sum would grow quadratically).
 __global__ __launch_bounds__(1024) void trace_scan(const TraceParams p) {
-    __shared__ int s_part[1024];
-    const int tid = threadIdx.x;
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.bounce == 0 ? p.PT : p.n_live[p.bounce];
     const int nb = (n + 255) / 256;                            // workgroups of the bounce that hold paths
-    const int per = (nb + 1023) / 1024;
-    const int lo = tid * per, hi = min(nb, lo + per);
-    for (int f = -1; f < p.nframes; f++) {                     // f = -1: all frames together (cnt), then frame f (cntf)
-        int* a = f < 0 ? p.cnt : p.cntf + f;
-        const int stride = f < 0 ? 1 : BMAX;
-        int sum = 0;
-        for (int k = lo; k < hi; k++) sum += a[k * stride];
-        __syncthreads();
-        s_part[tid] = sum;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = tid >= o ? s_part[tid - o] : 0;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
+    const int f = (int)blockIdx.x - 1;
+    int* a = f < 0 ? p.cnt : p.cntf + f;
+    const int stride = f < 0 ? 1 : BMAX;
+    int carry = 0;                                             // sum of everything before the current 1024-entry block
+    for (int k0 = 0; k0 < nb; k0 += 1024) {
+        const int k = k0 + tid;
+        const int c = k < nb ? a[k * stride] : 0;
+        int incl = c;                                          // inclusive scan inside the wave
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
         }
-        int run = s_part[tid] - sum;
-        for (int k = lo; k < hi; k++) { const int c = a[k * stride]; a[k * stride] = run; run += c; }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; w++) { const int v = s_wsum[w]; if (w < wave) woff += v; total += v; }
+        if (k < nb) a[k * stride] = carry + woff + incl - c;
+        carry += total;
+        __syncthreads();
     }
 }
 
@@ -1374,7 +1375,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[1], st));
         if (b + 1 < depth) {
-            if (nframes > 1) hipLaunchKernelGGL(trace_scan, dim3(1), dim3(1024), 0, st, p);
+            if (nframes > 1) hipLaunchKernelGGL(trace_scan, dim3(1 + nframes), dim3(1024), 0, st, p);
             hipLaunchKernelGGL(trace_compact, dim3(nblk), dim3(256), 0, st, p);
             cur = nxt;
             if (sortmat) {                                      // compacted list -> sorted list (thrust::sort_by_key, :508-510)

@@ -328,30 +328,34 @@ def main():
                      "layers": [arch.layer_table()[l][0] for l in prof_layers]}
         # ---- bounce kernel (bounces 1 .. depth-1 share one instantiation; bounce 0 is its own)
         tr_ms, tr_calls = ctx.trace_profile_end(depth)
-        nb = [float(v) for v in n_live[:depth]]
+        last_fr = max(1, int(n_live[0]) // P)                                # frames of the last trace call
+        nb = [float(v) / last_fr for v in n_live[:depth]]                    # live paths per bounce, per frame
         late = [b for b in range(1, depth) if nb[b] > 0]
         tr_roof = None
         if tr_calls and late:
-            # a recorded trace covers B frames when batched: times are per launch, bytes and n_live per launch too
+            # every trace call of the timed region is recorded when batched (calls can hold different numbers of frames: the
+            # tail of the sequence), every 4th single-frame call otherwise: times per call, bytes per frame x frames per call
+            fpc = args.steps / tr_calls if B > 1 else 1.0                    # frames per recorded call (mean)
             t_late = float(sum(tr_ms[b] for b in late)) / tr_calls          # ms per trace call in the later-bounce launches
-            by_late = sum(nb[b] * 160.0 for b in late)                      # N_b x 160 B per bounce
+            by_late = sum(nb[b] * 160.0 for b in late) * fpc                # N_b x 160 B per bounce
             t_first = float(tr_ms[0]) / tr_calls
-            by_first = nb[0] * 160.0 + nb[0] * 64.0                         # + G-buffer write and image RMW, once per frame
+            by_first = (nb[0] * 160.0 + nb[0] * 64.0) * fpc                 # + G-buffer write and image RMW, once per frame
             name = ctx.trace_kernel_name(1)
             g_late = by_late / (t_late * 1e-3) / 1e9 if t_late > 0 else 0.0
             tr_roof = {"bound": "hbm", "achieved": round(g_late, 1), "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
                        "frac": round(g_late * 1e9 / MI355X_HBM_BPS, 5), "traffic": pmc_traffic(name),
-                       "kernel": name, "launches_per_frame": len(late), "avg_launch_ms": round(t_late / len(late), 5),
-                       "ms_per_frame": round(t_late / B, 4), "frames_per_launch": B, "launches_timed": tr_calls * len(late),
+                       "kernel": name, "launches_per_frame": round(len(late) / fpc, 3), "avg_launch_ms": round(t_late / len(late), 5),
+                       "ms_per_frame": round(t_late / fpc, 4), "frames_per_launch": round(fpc, 2), "launches_timed": tr_calls * len(late),
                        "algorithmic_bytes_per_launch": by_late / len(late),
                        "byte_model": "SURVEY 8d: sum over bounces of N_b x 160 B (44 B state read + 44 B write, 36 B hit record "
                                      "write + read of the reference's layout); BVH and triangle fetches are overhead, not algorithmic",
                        "first_bounce": {"kernel": ctx.trace_kernel_name(0), "avg_launch_ms": round(t_first, 5),
-                                        "algorithmic_bytes": by_first,
+                                        "algorithmic_bytes_per_launch": by_first,
                                         "achieved_GBps": round(by_first / (t_first * 1e-3) / 1e9, 1) if t_first > 0 else 0.0},
-                       "rays_per_frame": int(sum(nb) / B), "grays_per_s": round(sum(nb) / ((t_late + t_first) * 1e-3) / 1e9, 3),
-                       "note": "latency-bound BVH walk: a wave runs ~60 dependent node/leaf steps per bounce (tools/trace_stats.py); "
-                               "the HBM roof is reported because north_star asks for it, it is not what bounds this kernel"}
+                       "rays_per_frame": int(sum(nb)), "grays_per_s": round(sum(nb) * fpc / ((t_late + t_first) * 1e-3) / 1e9, 3),
+                       "note": "latency-bound BVH walk: a launch lasts as long as its slowest wave's chain of dependent node / leaf "
+                               "fetches (tools/trace_stats.py); the HBM roof is reported because north_star asks for it, it is "
+                               "not what bounds this kernel"}
         if tr_roof and tr_roof["ms_per_frame"] > conv_roof["ms_per_frame"]:
             roof, other = tr_roof, conv_roof
         else:

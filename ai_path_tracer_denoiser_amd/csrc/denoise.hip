@@ -506,6 +506,24 @@ __device__ __forceinline__ void quad_transpose_dpp(float (&r)[4], int lane) {
     }
 }
 
+// -DAIPT_CONV_PHASES: cycle stamps of wave 0 of every workgroup of the launches whose (W, nchunks, cout) match g_conv_key,
+// summed per phase (tools/conv_phases.py); compiled out of the product build.
+#ifdef AIPT_CONV_PHASES
+__device__ unsigned long long g_conv_phase[16];
+__device__ unsigned int g_conv_key;
+#define CPH_INIT() const bool cph_on = (threadIdx.x == 0) && g_conv_key == (((unsigned)g.W << 16) | ((unsigned)g.nchunks << 8) | (unsigned)g.cout); \
+    unsigned long long cph_t = __builtin_amdgcn_s_memtime(), cph_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long cph_t0 = cph_t
+#define CPH(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); cph_acc[k] += now_ - cph_t; cph_t = now_; } while (0)
+#define CPH_WAITVM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define CPH_END() do { if (cph_on) { for (int k_ = 0; k_ < 14; k_++) atomicAdd(&g_conv_phase[k_], cph_acc[k_]); \
+    atomicAdd(&g_conv_phase[14], __builtin_amdgcn_s_memtime() - cph_t0); atomicAdd(&g_conv_phase[15], 1ull); } } while (0)
+#else
+#define CPH_INIT() do {} while (0)
+#define CPH(k) do {} while (0)
+#define CPH_WAITVM() do {} while (0)
+#define CPH_END() do {} while (0)
+#endif
+
 // PLANAR: source a is a planar tensor [C][h][w] (the network input = the G-buffer contract): four 4-byte loads per staging
 // unit instead of one 16-byte load, no separate layout pass over the input.
 // W16: fp16 conv weights (BASELINE configs[4], AIPT_DN_IMPL_MFMA_F16W): the weights are the fp16 roundings the hi half
@@ -526,6 +544,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
     if (!tile.valid) return;
+    CPH_INIT();
     const int tx0 = tile.tx * 32, ty0 = tile.ty * TH;
     const int n0 = tile.gz * 32;
     const int H = g.H, W = g.W;
@@ -534,22 +553,6 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const int sw = up ? (W >> 1) : W;
     const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;      // bytes of one channel quad
     const int ca16 = g.ca16;
-
-    // BN coefficient table over the K16 concat space ((0,0) for pad channels) + zeroed halo image
-    for (int kc = tid; kc < g.nchunks * KH; kc += NT) {
-        const bool fa = kc < ca16 * KH;
-        const int c = fa ? kc : kc - ca16 * KH;
-        const ConvSrc& s = fa ? g.a : g.b;
-        float2 t = make_float2(0.0f, 0.0f);
-        if (c < s.C) t = bn_ab(s.bn, c);
-        tab_a[kc] = t.x;
-        tab_b[kc] = t.y;
-    }
-    // zeroed halo image: only tiles whose halo leaves the image need it (out-of-image units never write); an interior tile
-    // overwrites every byte the MFMA phase reads, every chunk
-    const bool halo_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + 33 <= W;
-    if (!halo_inside)
-        for (int i = tid; i < 2 * Cfg::A_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
 
     // chunk-invariant staging units: this thread stages channel quad q of halo pixels slot, slot+TPQ, ...
     const int q = tid / TPQ, slot = tid - q * TPQ;
@@ -645,12 +648,40 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 *reinterpret_cast<u32x4*>(Bhi + w_lds[j]) = pw[j];
     };
 
+    CPH(0);
     fetch(0);
+    CPH(1);
+    CPH_WAITVM();
+    CPH(10);
+    // BN coefficient table over the K16 concat space ((0,0) for pad channels), behind the first chunk's loads: its own
+    // round trip to the statistics (10 k cycles of a 55 k-cycle workgroup when it ran first) overlaps theirs
+    for (int kc = tid; kc < g.nchunks * KH; kc += NT) {
+        const bool fa = kc < ca16 * KH;
+        const int c = fa ? kc : kc - ca16 * KH;
+        const ConvSrc& s = fa ? g.a : g.b;
+        float2 t = make_float2(0.0f, 0.0f);
+        if (c < s.C) t = bn_ab(s.bn, c);
+        tab_a[kc] = t.x;
+        tab_b[kc] = t.y;
+    }
+    CPH(11);
+    // zeroed halo image: only tiles whose halo leaves the image need it (out-of-image units never write); an interior tile
+    // overwrites every byte the MFMA phase reads, every chunk
+    const bool halo_inside = ty0 >= 1 && ty0 + TH + 1 <= H && tx0 >= 1 && tx0 + 33 <= W;
+    if (!halo_inside)
+        for (int i = tid; i < 2 * Cfg::A_BYTES / 16; i += NT) reinterpret_cast<u32x4*>(smem)[i] = u32x4{0u, 0u, 0u, 0u};
+    CPH(12);
     __syncthreads();                                           // tables and the zeroed halo visible
+    CPH(2);
     for (int chunk = 0; chunk < g.nchunks; chunk++) {
+        CPH_WAITVM();
+        CPH(3);
         stash(chunk);
+        CPH(4);
         __syncthreads();
+        CPH(5);
         if (chunk + 1 < g.nchunks) fetch(chunk + 1);
+        CPH(6);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
             f16x8 fah[RW + 2], fal[RW + 2];
@@ -673,7 +704,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 }
             }
         }
+        CPH(7);
         __syncthreads();
+        CPH(8);
     }
 
     // ---- epilogue.  D fragment (32x32): register k of lane l = pixel (k&3) + 8*(k>>2) + 4*(l>>5), channel l&31.
@@ -748,6 +781,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             }
         }
     }
+    CPH(9);
+    CPH_END();
 }
 
 // -------------------------------------------------------------------------------------------------- few-output conv
@@ -1093,6 +1128,7 @@ static long f16_small_min_pixels() {
     static const long v = getenv("AIPT_F16_SMALL_MINPIX") ? atol(getenv("AIPT_F16_SMALL_MINPIX")) : 0;
     return v;
 }
+static inline bool w16_mode(const DenoiseState* s) { return s->impl == AIPT_DN_IMPL_MFMA_F16W; }
 static inline bool impl_is_f16(int impl) { return impl == AIPT_DN_IMPL_MFMA_F16X3 || impl == AIPT_DN_IMPL_MFMA_F16W; }
 static long f16_min_pixels() {
     static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
@@ -1278,7 +1314,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         // tile rows = waves per workgroup: 8 on the big levels; the small levels (< f16_min_pixels) have too few 8 x 32 tiles
         // to fill 256 CUs and run 2- or 4-row tiles
         static const int small_rows = getenv("AIPT_F16_SMALL_ROWS") ? atoi(getenv("AIPT_F16_SMALL_ROWS")) : 4;
-        const int rows = (long)H * W >= f16_min_pixels() ? 8 : small_rows;
+        static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
+        const bool big = (long)H * W >= f16_min_pixels();
+        const int rows = big ? 8 : small_rows;
         const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
@@ -1286,7 +1324,6 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
         f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
-        static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
         if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
@@ -1755,3 +1792,19 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
 }
 
 }  // extern "C"
+
+#ifdef AIPT_CONV_PHASES
+// debug build only (not in include/aiptd.h): key != 0 selects the launches to stamp and zeroes the sums; key == 0 reads them
+extern "C" int aipt_debug_conv_phases(aipt_ctx* ctx, unsigned long long* out16, unsigned key) {
+    AIPT_CHECK_CTX(ctx);
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    if (key) {
+        unsigned long long z[16] = {0};
+        AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_conv_phase), z, sizeof z));
+        AIPT_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_conv_key), &key, sizeof key));
+    } else if (out16) {
+        AIPT_HIP(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_conv_phase), 128));
+    }
+    return AIPT_OK;
+}
+#endif

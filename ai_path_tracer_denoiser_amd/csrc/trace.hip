@@ -477,15 +477,102 @@ struct WalkStack {
 // the per-lane stack.  Box test per child: the ray's direction signs pick the entry and the exit plane of every axis once per
 // node (on the packed 4-child words), then t = fma(q, scale/d, (p - o)/d) on the 8-bit coordinate q, max3 / min3 -- 14 VALU
 // operations per child; the fma's error corresponds to ~1e-6 in space, far inside the boxes' padding.
+struct WalkRay {
+    v3 o, d;
+    float ix, iy, iz;
+    bool negx, negy, negz;
+    float t_min;
+    int best_face, best_slot;
+    __device__ __forceinline__ void start(v3 o_, v3 d_, float t_bound) {
+        o = o_; d = d_;
+        ix = 1.0f / d.x; iy = 1.0f / d.y; iz = 1.0f / d.z;
+        negx = __float_as_uint(ix) >> 31; negy = __float_as_uint(iy) >> 31; negz = __float_as_uint(iz) >> 31;
+        t_min = t_bound; best_face = -1; best_slot = -1;
+    }
+};
+constexpr int WALK_DONE = BVH_EMPTY;
+
+// one inner-node visit: box tests of the four children, nearest-first order, the nearest becomes `cur`, the others wait on
+// the stack (or `cur` pops the stack / becomes WALK_DONE when no child is hit)
+__device__ __forceinline__ void walk_node(const uint4* nodes, const WalkRay& r, WalkStack& st, int& cur) {
+    const uint4* nd = nodes + (unsigned)cur * 4u;
+    const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
+    const float sx = __uint_as_float((w0.w & 0xffu) << 23) * r.ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * r.iy,
+                sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * r.iz;
+    const float bx = (__uint_as_float(w0.x) - r.o.x) * r.ix, by = (__uint_as_float(w0.y) - r.o.y) * r.iy,
+                bz = (__uint_as_float(w0.z) - r.o.z) * r.iz;
+    // entry / exit planes of the four children, per axis (qlo = w1.xyz, qhi = w1.w, w2.x, w2.y)
+    const uint32_t nx = r.negx ? w1.w : w1.x, fx = r.negx ? w1.x : w1.w;
+    const uint32_t ny = r.negy ? w2.x : w1.y, fy = r.negy ? w1.y : w2.x;
+    const uint32_t nz = r.negz ? w2.y : w1.z, fz = r.negz ? w1.z : w2.y;
+    float key[4];
+    int ref[4] = {(int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float n = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nx, k), sx, bx), __builtin_fmaf(ubyte_f(ny, k), sy, by)),
+                              __builtin_fmaf(ubyte_f(nz, k), sz, bz));
+        const float f = fminf(fminf(__builtin_fmaf(ubyte_f(fx, k), sx, bx), __builtin_fmaf(ubyte_f(fy, k), sy, by)),
+                              __builtin_fmaf(ubyte_f(fz, k), sz, bz));
+        const bool h = ref[k] != BVH_EMPTY && !(f < 0.0f || n > f || n > r.t_min);    // NaN -> visit
+        key[k] = h ? fmaxf(n, -FLT_MAX) : INFINITY;                                    // a NaN key of a hit sorts first
+    }
+    cas(key[0], ref[0], key[1], ref[1]);
+    cas(key[2], ref[2], key[3], ref[3]);
+    cas(key[0], ref[0], key[2], ref[2]);
+    cas(key[1], ref[1], key[3], ref[3]);
+    cas(key[1], ref[1], key[2], ref[2]);
+    if (__builtin_expect(st.sp + 3 > STACK_LDS, 0)) {   // rare: some of the pushes may go to the overflow area
+        if (key[3] < INFINITY) st.push(ref[3]);
+        if (key[2] < INFINITY) st.push(ref[2]);
+        if (key[1] < INFINITY) st.push(ref[1]);
+    } else {                                            // farthest first: the stack pops the nearest
+        if (key[3] < INFINITY) st.lds[st.sp++ * 256] = ref[3];
+        if (key[2] < INFINITY) st.lds[st.sp++ * 256] = ref[2];
+        if (key[1] < INFINITY) st.lds[st.sp++ * 256] = ref[1];
+    }
+#if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
+    atomicMax(&g_trace_stats[6], (unsigned long long)st.sp);
+    if (st.sp > 8) STAT_ADD(7, 1);
+    if (st.sp > 12) STAT_ADD(15, 1);
+#endif
+    if (key[0] < INFINITY) cur = ref[0];
+    else cur = st.sp ? st.pop() : WALK_DONE;
+}
+
+// one leaf: the reference's triangle test on its (<= 7) triangles, two per memory round trip
+__device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur) {
+    const int v = -cur - 1, first = v >> 3, cnt = v & 7;
+    STAT_ADD(2, cnt); STAT_ADD(4, 1); STAT_WAVE(3);
+    for (int k = 0; k < cnt; k += 2) {
+        const bool two = k + 1 < cnt;
+        const uint4* tr = tris + (unsigned)(first + k) * 3u;
+        const uint4* tr2 = two ? tr + 3 : tr;           // odd count: the second test repeats the first (no effect)
+        const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
+        const uint4 q0 = tr2[0], q1 = tr2[1], q2 = tr2[2];
+        const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                      V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                      V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), r.o, r.d);
+        const int fa = (int)r2.y;
+        if (ta > 0.0f && (r.t_min > ta || (r.t_min == ta && r.best_face >= 0 && fa < r.best_face))) {
+            r.t_min = ta; r.best_face = fa; r.best_slot = first + k;
+        }
+        const float tb = triHitT_flat(V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
+                                      V(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)),
+                                      V(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)), r.o, r.d);
+        const int fb = (int)q2.y;
+        if (tb > 0.0f && (r.t_min > tb || (r.t_min == tb && r.best_face >= 0 && fb < r.best_face))) {
+            r.t_min = tb; r.best_face = fb; r.best_slot = first + k + (two ? 1 : 0);
+        }
+    }
+}
+
 __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot) {
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
-    const bool negx = __float_as_uint(ix) >> 31, negy = __float_as_uint(iy) >> 31, negz = __float_as_uint(iz) >> 31;
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
     const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
-    int best_face = -1;
+    WalkRay r;
+    r.start(o, d, t_min);
     int cur = 0;
     st.sp = 0;
-    constexpr int DONE = BVH_EMPTY;
 #ifdef AIPT_TRACE_STATS
     int my_visits = 0;
 #define STAT_MINE() my_visits++
@@ -495,78 +582,15 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
     while (true) {
         while (cur >= 0) {
             STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
-            const uint4* nd = nodes + (unsigned)cur * 4u;
-            const uint4 w0 = nd[0], w1 = nd[1], w2 = nd[2], w3 = nd[3];
-            const float sx = __uint_as_float((w0.w & 0xffu) << 23) * ix, sy = __uint_as_float(((w0.w >> 8) & 0xffu) << 23) * iy,
-                        sz = __uint_as_float(((w0.w >> 16) & 0xffu) << 23) * iz;
-            const float bx = (__uint_as_float(w0.x) - o.x) * ix, by = (__uint_as_float(w0.y) - o.y) * iy,
-                        bz = (__uint_as_float(w0.z) - o.z) * iz;
-            // entry / exit planes of the four children, per axis (qlo = w1.xyz, qhi = w1.w, w2.x, w2.y)
-            const uint32_t nx = negx ? w1.w : w1.x, fx = negx ? w1.x : w1.w;
-            const uint32_t ny = negy ? w2.x : w1.y, fy = negy ? w1.y : w2.x;
-            const uint32_t nz = negz ? w2.y : w1.z, fz = negz ? w1.z : w2.y;
-            float key[4];
-            int ref[4] = {(int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float n = fmaxf(fmaxf(__builtin_fmaf(ubyte_f(nx, k), sx, bx), __builtin_fmaf(ubyte_f(ny, k), sy, by)),
-                                      __builtin_fmaf(ubyte_f(nz, k), sz, bz));
-                const float f = fminf(fminf(__builtin_fmaf(ubyte_f(fx, k), sx, bx), __builtin_fmaf(ubyte_f(fy, k), sy, by)),
-                                      __builtin_fmaf(ubyte_f(fz, k), sz, bz));
-                const bool h = ref[k] != BVH_EMPTY && !(f < 0.0f || n > f || n > t_min);      // NaN -> visit
-                key[k] = h ? fmaxf(n, -FLT_MAX) : INFINITY;                                    // a NaN key of a hit sorts first
-            }
-            cas(key[0], ref[0], key[1], ref[1]);
-            cas(key[2], ref[2], key[3], ref[3]);
-            cas(key[0], ref[0], key[2], ref[2]);
-            cas(key[1], ref[1], key[3], ref[3]);
-            cas(key[1], ref[1], key[2], ref[2]);
-            if (__builtin_expect(st.sp + 3 > STACK_LDS, 0)) {   // rare: some of the pushes may go to the overflow area
-                if (key[3] < INFINITY) st.push(ref[3]);
-                if (key[2] < INFINITY) st.push(ref[2]);
-                if (key[1] < INFINITY) st.push(ref[1]);
-            } else {                                            // farthest first: the stack pops the nearest
-                if (key[3] < INFINITY) st.lds[st.sp++ * 256] = ref[3];
-                if (key[2] < INFINITY) st.lds[st.sp++ * 256] = ref[2];
-                if (key[1] < INFINITY) st.lds[st.sp++ * 256] = ref[1];
-            }
-#if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
-            atomicMax(&g_trace_stats[6], (unsigned long long)st.sp);
-            if (st.sp > 8) STAT_ADD(7, 1);
-            if (st.sp > 12) STAT_ADD(15, 1);
-#endif
-            if (key[0] < INFINITY) cur = ref[0];
-            else cur = st.sp ? st.pop() : DONE;
+            walk_node(nodes, r, st, cur);
         }
-        if (cur == DONE) break;
-        {
-            const int v = -cur - 1, first = v >> 3, cnt = v & 7;
-            STAT_ADD(2, cnt); STAT_ADD(4, 1); STAT_WAVE(3);
-            for (int k = 0; k < cnt; k += 2) {
-                const bool two = k + 1 < cnt;
-                const uint4* tr = tris + (unsigned)(first + k) * 3u;
-                const uint4* tr2 = two ? tr + 3 : tr;           // odd count: the second test repeats the first (no effect)
-                const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
-                const uint4 q0 = tr2[0], q1 = tr2[1], q2 = tr2[2];
-                const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                              V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
-                                              V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), o, d);
-                const int fa = (int)r2.y;
-                if (ta > 0.0f && (t_min > ta || (t_min == ta && best_face >= 0 && fa < best_face))) {
-                    t_min = ta; best_face = fa; best_slot = first + k;
-                }
-                const float tb = triHitT_flat(V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
-                                              V(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)),
-                                              V(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)), o, d);
-                const int fb = (int)q2.y;
-                if (tb > 0.0f && (t_min > tb || (t_min == tb && best_face >= 0 && fb < best_face))) {
-                    t_min = tb; best_face = fb; best_slot = first + k + (two ? 1 : 0);
-                }
-            }
-        }
-        cur = st.sp ? st.pop() : DONE;
-        if (cur == DONE) break;
+        if (cur == WALK_DONE) break;
+        walk_leaf(tris, r, cur);
+        cur = st.sp ? st.pop() : WALK_DONE;
+        if (cur == WALK_DONE) break;
     }
+    t_min = r.t_min;
+    best_slot = r.best_slot;
 #if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
     atomicMax(&g_trace_stats[5], (unsigned long long)my_visits);
     const int bucket = my_visits <= 4 ? 8 : my_visits <= 8 ? 9 : my_visits <= 16 ? 10 : my_visits <= 32 ? 11 : my_visits <= 64 ? 12 : my_visits <= 128 ? 13 : 14;
@@ -574,41 +598,225 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
 #endif
 }
 
+// the full face record behind leaf slot `slot` (five 16-byte loads)
+__device__ __forceinline__ void load_leaf_face(const TraceParams& p, int slot, DevFace& f) {
+    const uint4* fp = reinterpret_cast<const uint4*>(p.lfaces + slot);
+    const uint4 q0 = fp[0], q1 = fp[1], q2 = fp[2], q3 = fp[3], q4 = fp[4];
+    uint32_t* fw = reinterpret_cast<uint32_t*>(&f);
+    fw[0] = q0.x; fw[1] = q0.y; fw[2] = q0.z; fw[3] = q0.w; fw[4] = q1.x; fw[5] = q1.y; fw[6] = q1.z; fw[7] = q1.w;
+    fw[8] = q2.x; fw[9] = q2.y; fw[10] = q2.z; fw[11] = q2.w; fw[12] = q3.x; fw[13] = q3.y; fw[14] = q3.z; fw[15] = q3.w;
+    fw[16] = q4.x; fw[17] = q4.y; fw[18] = q4.z;
+}
+
+// generateRayFromCamera (pathtrace.cu:155-182) for pixel `pix` of frame `fr`
+__device__ __forceinline__ void camera_ray(const TraceParams& p, int pix, int fr, v3& o, v3& d) {
+    const int x = pix % p.W, y = pix / p.W;
+    const aipt_camera& cam = p.cams[fr];
+    const v3 view = V(cam.view[0], cam.view[1], cam.view[2]);
+    const v3 right = V(cam.right[0], cam.right[1], cam.right[2]);
+    const v3 up = V(cam.up[0], cam.up[1], cam.up[2]);
+    o = V(cam.position[0], cam.position[1], cam.position[2]);
+    float jx = 0.0f, jy = 0.0f;
+    if (p.flags & AIPT_TRACE_AA) {
+        uint32_t rng = make_seed(p.iter, pix, 0);    // uninitialised in the reference, defined as 0
+        jx = u01(rng, -0.5f, 0.5f);
+        jy = u01(rng, -0.5f, 0.5f);
+    }
+    float sx = (float)x - (float)cam.resolution[0] * 0.5f;
+    float sy = (float)y - (float)cam.resolution[1] * 0.5f;
+    if (p.flags & AIPT_TRACE_AA) { sx = sx + jx; sy = sy + jy; }
+    d = vnormalize(vsub(vsub(view, vscale(vscale(right, cam.pixelLength[0]), sx)),
+                        vscale(vscale(up, cam.pixelLength[1]), sy)));
+}
+
+// ---- pooled walk (POOL instantiations of the bounce kernel).  A wave that walks 64 rays to the end runs the UNION of their
+// walks: 47 node-loop trips for 7 node visits per ray on the atrium (SIMD efficiency 0.16), because a few rays of every wave
+// take 30-70 visits.  With a batch of frames in one launch there are many more rays than lanes, so a workgroup takes
+// POOL_BLOCKS x 256 paths, lists those that enter the mesh box in an LDS pool and its four waves walk the pool: a lane whose
+// ray is finished stores the result and, once POOL_REFILL lanes of its wave are idle, they take the next rays of the pool.
+// Per-path arithmetic is that of the fused walk (walk_node / walk_leaf), started without the primitives' distance bound
+// (the nearest face is the nearest face; the caller lets it replace a primitive hit only when strictly nearer, as the
+// reference's loop does), so results do not depend on how rays were assigned to lanes.
+#ifndef AIPT_POOL_BLOCKS
+#define AIPT_POOL_BLOCKS 4
+#endif
+constexpr int POOL_BLOCKS = AIPT_POOL_BLOCKS;
+#ifndef AIPT_POOL_REFILL
+#define AIPT_POOL_REFILL 16
+#endif
+#ifndef AIPT_POOL_LEAF
+#define AIPT_POOL_LEAF 16
+#endif
+constexpr int POOL_REFILL = AIPT_POOL_REFILL;      // idle lanes of a wave that trigger a refill
+constexpr int POOL_LEAF = AIPT_POOL_LEAF;          // lanes waiting at a leaf that trigger a leaf step
+__device__ __forceinline__ int pool_blocks(int n) {                 // 256-path blocks per workgroup for n live paths
+    const int k = n / (256 * 512);                                  // keep >= 512 workgroups
+    return k < 1 ? 1 : k > POOL_BLOCKS ? POOL_BLOCKS : k;
+}
+template <bool FIRST>
+__device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int2* s_res,
+                                          WalkStack& st, int lane) {
+    const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
+    const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
+    const float4* S0 = p.st; const float4* S1 = p.st + p.PS;
+    WalkRay r;
+    r.start(V(0, 0, 0), V(1, 1, 1), FLT_MAX);
+    int cur = WALK_DONE, lid = -1;
+    bool exhausted = pool_n == 0;
+    st.sp = 0;
+    while (true) {
+        if (cur == WALK_DONE && lid >= 0) {                         // finished since the last look: hand the result over
+            s_res[lid] = make_int2(__float_as_int(r.t_min), r.best_slot);
+            lid = -1;
+        }
+        const unsigned long long idle = __ballot(cur == WALK_DONE);
+        const int nidle = __popcll(idle);
+        if (!exhausted && (nidle >= POOL_REFILL)) {
+            int base = 0;
+            if (lane == (int)__ffsll((long long)idle) - 1) base = atomicAdd(s_head, nidle);
+            base = __shfl(base, (int)__ffsll((long long)idle) - 1);
+            if (cur == WALK_DONE) {
+                const int k = base + __popcll(idle & ((1ull << lane) - 1ull));
+                if (k < pool_n) {
+                    lid = s_pool[k];
+                    const int i = s_res[lid].x;                     // the path index, parked there by the listing phase
+                    v3 o, d;
+                    if (FIRST) {
+                        int pix = i, fr = 0;
+                        if (p.nframes > 1) { pix = i / p.nframes; fr = i - pix * p.nframes; }
+                        camera_ray(p, pix, fr, o, d);
+                    } else {
+                        const float4 a = S0[i], b = S1[i];
+                        o = V(a.x, a.y, a.z);
+                        d = V(a.w, b.x, b.y);
+                    }
+                    r.start(o, d, FLT_MAX);
+                    cur = 0;
+                    st.sp = 0;
+                }
+            }
+            exhausted = base + nidle >= pool_n;
+        }
+        // one step for the lanes of one kind: inner nodes, unless POOL_LEAF lanes wait at a leaf (or nobody is at a node).
+        // (The fused walk's "descend until every lane holds a leaf" keeps a lane that found its leaf early idle for the
+        // whole descent of the others; with refilled lanes at every depth that would be most of the time.)
+        const int nl = __popcll(__ballot(cur < 0 && cur != WALK_DONE));
+        const bool any_node = __ballot(cur >= 0) != 0ull;
+        if (!any_node && nl == 0) {
+            if (exhausted) break;
+            continue;                                               // (unreachable: an all-idle wave always refills)
+        }
+        if (nl >= POOL_LEAF || !any_node) {
+            if (cur < 0 && cur != WALK_DONE) {
+                walk_leaf(tris, r, cur);
+                cur = st.sp ? st.pop() : WALK_DONE;
+            }
+        } else if (cur >= 0) {
+            STAT_ADD(0, 1); STAT_WAVE(1);
+            walk_node(nodes, r, st, cur);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- the bounce kernel
 // MESH = false drops the triangle path (and its LDS traversal stack) from the instantiation used for primitive-only scenes.
 #ifndef AIPT_TRACE_OCC
 #define AIPT_TRACE_OCC 1
 #endif
-template <bool FIRST, bool MESH>
+template <bool FIRST, bool MESH, bool POOL = false>
 __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
+    static_assert(MESH || !POOL, "the pool holds mesh walks");
     __shared__ int s_wave[4];
-    // dynamic LDS: [MESH: STACK_LDS x 256 stack words][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)], sized by the launch
+    __shared__ int s_pool_n, s_head;
+    // dynamic LDS: [MESH: STACK_LDS x 256 stack words][POOL: pool, results][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)],
+    // sized by the launch
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     int* s_stack = s_dyn;
-    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0));
+    int* s_pool = s_dyn + STACK_LDS * 256;                                            // POOL: local ids of the paths to walk
+    int2* s_res = reinterpret_cast<int2*>(s_pool + POOL_BLOCKS * 256);                // POOL: per local id (t, leaf slot)
+    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0) + (POOL ? POOL_BLOCKS * 256 * 3 : 0));
     aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     PHASE_INIT();
     const int P = p.P;
     float4* S0 = p.st; float4* S1 = p.st + p.PS; float4* S2 = p.st + 2 * p.PS;
+    // live paths entering the bounce (complete: the previous kernels on this stream have finished) and the 256-path blocks
+    // this workgroup advances: one, or up to POOL_BLOCKS consecutive ones with their mesh walks pooled
+    const int n_in = FIRST ? p.PT : p.n_live[p.bounce];
+    const int K = POOL ? pool_blocks(n_in) : 1;
+    const int vb0 = blockIdx.x * K;
+    if ((!FIRST || POOL) && vb0 * 256 >= n_in) {          // whole workgroup beyond the list
+        if ((int)(blockIdx.x * 256) >= n_in && (int)blockIdx.x < p.nblk) {     // (a lower block index belongs to a pooling workgroup)
+            if (tid == 0) p.cnt[blockIdx.x] = 0;
+            if (p.nframes > 1 && tid < p.nframes) p.cntf[blockIdx.x * BMAX + tid] = 0;
+        }
+        return;
+    }
 
     // ---- which path does this thread advance, and at which index would thrust::partition have left it?
     // Bounce 0: thread t = pixel t.  Later bounces walk the LIVE LIST written by trace_compact: entry t is the pixel of the
     // t-th live path in array order, so t is exactly the compacted array index that seeds the RNG (pathtrace.cu:351) --
     // every wave is full of live paths and the state planes are gathered/scattered through the pixel index.
+    // primitives and materials into LDS: the candidate loop and the shader index them per lane
+    const bool broad = p.ngeoms <= MAXG_LDS && !(p.flags & AIPT_TRACE_NO_BROAD_PHASE);
+    const bool mats_lds = p.nmats <= MAXM_LDS;
+    if (broad) {
+        const int nw = p.ngeoms * (int)(sizeof(DevGeom) / 4);
+        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_geoms)[k] = reinterpret_cast<const int*>(p.geoms)[k];
+    }
+    if (mats_lds) {
+        const int nw = p.nmats * (int)(sizeof(aipt_material) / 4);
+        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
+    }
+    if (POOL && tid == 0) { s_pool_n = 0; s_head = 0; }
+    __syncthreads();
+    PHASE(0);
+
+    const bool walk_mesh = MESH && !(FIRST && p.cache_mode == 2) && p.nfaces && !(p.flags & 0x40000000u);
+    if (POOL) {
+        // ---- list the paths of this workgroup's blocks that enter the mesh box, walk them all, leave (t, leaf slot) per path
+        for (int j = 0; j < K; j++) {
+            const int t = (vb0 + j) * 256 + tid;
+            const bool alive = t < n_in;
+            const int i = FIRST ? t : (alive ? p.live_in[t] : 0);
+            bool walker = false;
+            if (alive && walk_mesh && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
+                v3 o, d;
+                if (FIRST) {
+                    int pix = i, fr = 0;
+                    if (p.nframes > 1) { pix = i / p.nframes; fr = i - pix * p.nframes; }
+                    camera_ray(p, pix, fr, o, d);
+                } else {
+                    const float4 a = S0[i], b = S1[i];
+                    o = V(a.x, a.y, a.z);
+                    d = V(a.w, b.x, b.y);
+                }
+                walker = rayAABB(o, d, p.box);                      // RAY_CULLING true (:23, :258)
+            }
+            const unsigned long long m = __ballot(walker);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_pool_n, __popcll(m));
+            base = __shfl(base, 0);
+            s_res[j * 256 + tid] = make_int2(i, -1);                // the path index for the walker; "no face" for everyone else
+            if (walker) s_pool[base + __popcll(m & ((1ull << lane) - 1ull))] = j * 256 + tid;
+        }
+        __syncthreads();
+        WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0};
+        pool_walk<FIRST>(p, s_pool, s_pool_n, &s_head, s_res, st, lane);
+        __syncthreads();
+        PHASE(2);
+    }
+
+  for (int j = 0; j < K; j++) {                            // (body not re-indented: one pass per 256-path block)
+    const int vb = vb0 + j;
+    if (POOL && vb >= p.nblk) break;
     int i, idx, rem = 0;
     bool alive;
-    const int t = blockIdx.x * 256 + tid;
+    const int t = vb * 256 + tid;
     if (FIRST) {
         i = t; idx = t; alive = t < p.PT; rem = p.trace_depth;
     } else {
-        const int n = p.n_live[p.bounce];              // complete: the previous kernels on this stream have finished
-        if ((int)(blockIdx.x * 256) >= n) {            // whole workgroup beyond the list
-            if (tid == 0) p.cnt[blockIdx.x] = 0;
-            if (p.nframes > 1 && tid < p.nframes) p.cntf[blockIdx.x * BMAX + tid] = 0;
-            return;
-        }
-        alive = t < n;
+        alive = t < n_in;
         i = alive ? p.live_in[t] : 0;
         idx = (p.flags & AIPT_TRACE_COMPACT) ? t : i;
     }
@@ -626,42 +834,12 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         else idx = alive ? p.rank_in[t] : 0;
     }
 
-    // primitives and materials into LDS: the candidate loop and the shader index them per lane
-    const bool broad = p.ngeoms <= MAXG_LDS && !(p.flags & AIPT_TRACE_NO_BROAD_PHASE);
-    const bool mats_lds = p.nmats <= MAXM_LDS;
-    if (broad) {
-        const int nw = p.ngeoms * (int)(sizeof(DevGeom) / 4);
-        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_geoms)[k] = reinterpret_cast<const int*>(p.geoms)[k];
-    }
-    if (mats_lds) {
-        const int nw = p.nmats * (int)(sizeof(aipt_material) / 4);
-        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
-    }
-    __syncthreads();
-    PHASE(0);
-
     bool alive_after = false;
     if (alive) {
         v3 o, d, col;
         if (FIRST) {                                                             // generateRayFromCamera :155-182
-            const int x = pix % p.W, y = pix / p.W;
-            const aipt_camera& cam = p.cams[fr];
-            const v3 view = V(cam.view[0], cam.view[1], cam.view[2]);
-            const v3 right = V(cam.right[0], cam.right[1], cam.right[2]);
-            const v3 up = V(cam.up[0], cam.up[1], cam.up[2]);
-            o = V(cam.position[0], cam.position[1], cam.position[2]);
+            camera_ray(p, pix, fr, o, d);
             col = V(1.0f, 1.0f, 1.0f);
-            float jx = 0.0f, jy = 0.0f;
-            if (p.flags & AIPT_TRACE_AA) {
-                uint32_t rng = make_seed(p.iter, pix, 0);    // uninitialised in the reference, defined as 0
-                jx = u01(rng, -0.5f, 0.5f);
-                jy = u01(rng, -0.5f, 0.5f);
-            }
-            float sx = (float)x - (float)cam.resolution[0] * 0.5f;
-            float sy = (float)y - (float)cam.resolution[1] * 0.5f;
-            if (p.flags & AIPT_TRACE_AA) { sx = sx + jx; sy = sy + jy; }
-            d = vnormalize(vsub(vsub(view, vscale(vscale(right, cam.pixelLength[0]), sx)),
-                                vscale(vscale(up, cam.pixelLength[1]), sy)));
         } else {
             const float4 a = S0[i], b = S1[i], c = S2[i];
             o = V(a.x, a.y, a.z);
@@ -731,7 +909,16 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             }
         }
         PHASE(1);
-        if (MESH && !from_cache && p.nfaces && !(p.flags & 0x40000000u) && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
+        if (POOL && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
+            const int2 w = s_res[j * 256 + tid];                    // nearest face of the pooled walk (slot -1: none)
+            if (w.y >= 0 && t_min > __int_as_float(w.x)) {          // a face replaces a primitive hit only when strictly nearer (:262)
+                DevFace f;
+                load_leaf_face(p, w.y, f);
+                v3 tp, tn;
+                const float t = triangleTest(f, o, d, tp, tn);
+                t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
+            }
+        } else if (walk_mesh && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -745,13 +932,8 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 bvh4_nearest(p, o, d, st, t_min, best_slot);
                 if (best_slot >= 0) {
                     // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
-                    const uint4* fp = reinterpret_cast<const uint4*>(p.lfaces + best_slot);
-                    const uint4 q0 = fp[0], q1 = fp[1], q2 = fp[2], q3 = fp[3], q4 = fp[4];
                     DevFace f;
-                    uint32_t* fw = reinterpret_cast<uint32_t*>(&f);
-                    fw[0] = q0.x; fw[1] = q0.y; fw[2] = q0.z; fw[3] = q0.w; fw[4] = q1.x; fw[5] = q1.y; fw[6] = q1.z; fw[7] = q1.w;
-                    fw[8] = q2.x; fw[9] = q2.y; fw[10] = q2.z; fw[11] = q2.w; fw[12] = q3.x; fw[13] = q3.y; fw[14] = q3.z; fw[15] = q3.w;
-                    fw[16] = q4.x; fw[17] = q4.y; fw[18] = q4.z;
+                    load_leaf_face(p, best_slot, f);
                     v3 tp, tn;
                     const float t = triangleTest(f, o, d, tp, tn);
                     t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
@@ -821,16 +1003,17 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         PHASE(3);
     }
 
-    // ---- live count of this workgroup for the next bounce
+    // ---- live count of this 256-path block for the next bounce
     const unsigned long long m2 = __ballot(alive_after);
+    if (POOL) __syncthreads();                      // the previous block's readers of s_wave / s_cf are done
     if (lane == 0) s_wave[wave] = __popcll(m2);
     __syncthreads();
     if (tid == 0) {
         const int c = (s_wave[0] + s_wave[1]) + (s_wave[2] + s_wave[3]);
-        p.cnt[blockIdx.x] = c;
+        p.cnt[vb] = c;
         if (c) atomicAdd(&p.n_live[p.bounce + 1], c);
     }
-    if (p.nframes > 1) {                            // survivors per frame: this workgroup's counts (for the per-frame ranks) and the totals
+    if (p.nframes > 1) {                            // survivors per frame: this block's counts (for the per-frame ranks) and the totals
         __shared__ int s_cf[BMAX];
         if (tid < BMAX) s_cf[tid] = 0;
         __syncthreads();
@@ -840,10 +1023,11 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
         __syncthreads();
         if (tid < p.nframes) {
-            p.cntf[blockIdx.x * BMAX + tid] = s_cf[tid];
+            p.cntf[vb * BMAX + tid] = s_cf[tid];
             if (s_cf[tid]) atomicAdd(&p.n_live_f[(p.bounce + 1) * BMAX + tid], s_cf[tid]);
         }
     }
+  }
 }
 
 // Batched traces: exclusive prefix over the workgroups of the survivor counts, in place -- blockIdx 0: all frames together
@@ -1358,8 +1542,12 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     const bool mesh = s->nfaces > 0;
     const size_t lds_scene = (s->ngeoms <= MAXG_LDS ? sizeof(DevGeom) * s->ngeoms : 0) + (s->nmats <= MAXM_LDS ? sizeof(aipt_material) * s->nmats : 0);
     const size_t stack_bytes = (mesh ? (size_t)STACK_LDS * 256 * sizeof(int) : 0) + lds_scene;     // dynamic LDS of the bounce kernels
-    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s>", mesh ? "true" : "false");
-    snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s>", mesh ? "true" : "false");
+    // batched traces of a mesh scene pool their walks (see pool_walk); AIPT_TRACE_POOL=0/1 forces the choice (experiments)
+    static const int pool_env = getenv("AIPT_TRACE_POOL") ? atoi(getenv("AIPT_TRACE_POOL")) : -1;
+    const bool pool = mesh && (pool_env < 0 ? nframes > 1 : pool_env != 0);
+    const size_t pool_bytes = stack_bytes + (size_t)POOL_BLOCKS * 256 * 3 * sizeof(int);
+    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
+    snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
     int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
@@ -1369,7 +1557,9 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         if (nframes > 1) { p.rank_in = cur < 0 ? nullptr : s->d_rank[cur]; p.rank_out = s->d_rank[nxt]; }
         hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
-        if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
+        if (b == 0 && pool) hipLaunchKernelGGL((trace_bounce<true, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
+        else if (pool) hipLaunchKernelGGL((trace_bounce<false, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
+        else if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);

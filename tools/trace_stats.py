@@ -16,6 +16,7 @@ def main():
     import torch
     from ai_path_tracer_denoiser_amd import api, synth
     ntri = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 1           # frames traced together (interleaved batch)
     W, H, depth = 1280, 720, 8
     sc = api.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(W, H), depth=depth)
     stone = api.Material.from_buffer_copy(synth.STONE)
@@ -24,14 +25,24 @@ def main():
     box = api.AABB(); box.lb[:] = [float(v) for v in lb]; box.ub[:] = [float(v) for v in ub]
     ctx = api.Context(0)
     ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
-    g = torch.zeros(10, H, W, device="cuda")
+    from ai_path_tracer_denoiser_amd import dist as adist
+    cams = [sc.orbit(phi=adist.pan_phi(sc.phi, k)) for k in range(B)]
+    if B > 1:
+        ctx.trace_configure_batch(W, H, B)
+    g = torch.zeros(B, 10, H, W, device="cuda")
+
+    def trace(d):
+        if B > 1:
+            ctx.pathtrace_batch(cams, 1, d, g)
+        else:
+            ctx.pathtrace(sc.camera, 1, d, g[0])
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 16)()
     L = api.lib()
     prev = None
     for d in range(1, depth + 1 if not os.environ.get("PHASES_ONLY") else 1):              # depth d minus depth d-1 = bounce d-1 alone
         L.aipt_debug_trace_stats(ctx._h, out, 1)
-        ctx.pathtrace(sc.camera, 1, d, g)
+        trace(d)
         ctx.sync()
         ctx._ck(L.aipt_debug_trace_stats(ctx._h, out, 0))
         cur = np.array(list(out), np.float64)
@@ -48,7 +59,7 @@ def main():
     # phase cycle sums (one lane per wave): prologue, primitives, BVH walk + winner fetch, shade/scatter/store
     ph = (C.c_ulonglong * 16)()
     L.aipt_debug_trace_stats(ctx._h, ph, 1)
-    ctx.pathtrace(sc.camera, 1, depth, g)
+    trace(depth)
     ctx.sync()
     L.aipt_debug_trace_stats(ctx._h, ph, 2)
     v = np.array(list(ph)[:4], np.float64)

@@ -1099,16 +1099,30 @@ struct DenoiseState {
     bool have_weights = false;
     LayerW L[NLAYERS];
     int H = 0, W = 0;
-    Tensor In;                     // C4 copy of the planar network input
-    Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
-    Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
-    Tensor D1[6], D2[6];           // decoder k = 1..5
-    // BN sums of every conv layer, double-buffered by frame parity: the hidden states written in frame k are read in
-    // frame k+1, whose own sums go to the other set (one memset per frame instead of a finalize launch per conv)
+    // Two activation sets, alternating by frame: frame n works in A[n & 1] and reads the hidden states frame n-1 left in the
+    // other set.  That is what lets aipt_frames run consecutive frames of ONE recurrent sequence on two streams (below).
+    struct ActSet {
+        Tensor In;                     // C4 copy of the planar network input
+        Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
+        Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
+        Tensor D1[6], D2[6];           // decoder k = 1..5
+    } A[2];
+    int aset = 0;                      // set of the last frame (its Hid[] are the carried hidden states)
+    // BN sums of every conv layer, one set per frame in a ring of four: the hidden states written in frame n are read in
+    // frame n+1, whose own sums go to the next set (one memset per frame instead of a finalize launch per conv); with two
+    // frames in flight the set zeroed for frame n was last read by frame n-3, which the stream order has retired.
     static constexpr int STAT_SC = 128;                                    // channel stride (>= every cout)
     static constexpr size_t STAT_LAYER = (size_t)NSLOT * STAT_SC * 2;      // doubles per layer
-    double* stat[2] = {nullptr, nullptr};
-    int parity = 0;
+    static constexpr int STAT_SETS = 4;
+    double* stat[STAT_SETS] = {nullptr, nullptr, nullptr, nullptr};
+    int sset = 0;
+    // Frame pipelining (aipt_frames): frame n+1 may enter encoder level L as soon as frame n has left it (its hidden state of
+    // that level is complete), so the launches of two frames interleave on two streams and the many small launches of the
+    // deep levels and the decoder of one frame (a few dozen workgroups on 256 CUs) run beside the full-size layers of the other.
+    hipStream_t cur = nullptr;         // stream of the forward pass being enqueued
+    hipEvent_t ev_level[2][6] = {};    // [set][level]: the hidden state of that level is written
+    hipEvent_t ev_fence[2] = {};       // around a timed forward pass
+    bool ev_level_valid[2][6] = {};
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
     int num_cus = 256;
@@ -1175,7 +1189,17 @@ static void free_profile(DenoiseState* s) {
 static void free_activations(DenoiseState* s) {
     for (void* p : s->allocs) hipFree(p);
     s->allocs.clear();
-    s->stat[0] = s->stat[1] = nullptr;
+    for (int k = 0; k < DenoiseState::STAT_SETS; k++) s->stat[k] = nullptr;
+    for (int a = 0; a < 2; a++)
+        for (int l = 0; l < 6; l++) {
+            if (s->ev_level[a][l]) hipEventDestroy(s->ev_level[a][l]);
+            s->ev_level[a][l] = nullptr;
+            s->ev_level_valid[a][l] = false;
+        }
+    for (int k = 0; k < 2; k++) {
+        if (s->ev_fence[k]) hipEventDestroy(s->ev_fence[k]);
+        s->ev_fence[k] = nullptr;
+    }
     s->H = s->W = 0;
 }
 
@@ -1254,16 +1278,16 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin || A.C != L.ca)
         return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
-    double* const stat = batch ? s->stat[s->parity] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
+    double* const stat = batch ? s->stat[s->sset] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
     g.stat = stat; g.sc = DenoiseState::STAT_SC;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
-    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], ctx->stream));
+    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], s->cur));
     if (s->impl == AIPT_DN_IMPL_VALU) {
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_valu");
-        hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, ctx->stream, g);
+        hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, s->cur, g);
         if (batch)
-            hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, ctx->stream, dst.p, (size_t)H * W, stat);
+            hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, s->cur, dst.p, (size_t)H * W, stat);
     } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16) {
         // upsample + conv with 3 outputs on the split-fp16 kernel: half-resolution conv, 12 virtual channels, depth-to-space store
         ConvArgsH gh;
@@ -1280,7 +1304,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
-        hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, ctx->stream, gh);
+        hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, s->cur, gh);
     } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
         g.a.up = 0; g.b.up = 0;
@@ -1290,18 +1314,18 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const TileChoice t = choose_tile(g.H, g.W, 1);
         const dim3 grid((g.W + 16 * t.mbx - 1) / (16 * t.mbx), (g.H + 4 * t.rw - 1) / (4 * t.rw), 1);
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,1>", t.rw, t.mbx);
-        if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, ctx->stream);
-        else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, ctx->stream);
-        else launch_mfma<1, 1, 1>(g, grid, ctx->stream);
+        if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, s->cur);
+        else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, s->cur);
+        else launch_mfma<1, 1, 1>(g, grid, s->cur);
     } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         const int strips = ((W + 3) / 4) * H;
         const int nblk = (strips + 255) / 256;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3>");
-        hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, s->cur, g);
     } else if (L.cout == 3 && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
         const dim3 grid((W + 15) / 16, (H + 15) / 16);
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
-        hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, ctx->stream, g);
+        hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, s->cur, g);
     } else if (impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels()) {
         // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
         ConvArgsH gh;
@@ -1327,31 +1351,31 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
         if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
-            if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
-            else hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
-        } else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, ctx->stream, gh);
-        else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(grid_1d(grid.x, (H + 3) / 4, grid.z)), dim3(256), 0, ctx->stream, gh);
-        else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, ctx->stream, gh);
-        else if (rows == 4) hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
-        else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, ctx->stream, gh);
-        else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, ctx->stream, gh);
+            if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+        } else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+        else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(grid_1d(grid.x, (H + 3) / 4, grid.z)), dim3(256), 0, s->cur, gh);
+        else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, s->cur, gh);
+        else if (rows == 4) hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, s->cur, gh);
+        else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, s->cur, gh);
+        else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, s->cur, gh);
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
         const dim3 grid((W + 16 * t.mbx - 1) / (16 * t.mbx), (H + 4 * t.rw - 1) / (4 * t.rw), L.NB / t.nbb);
         const int key = t.rw * 100 + t.mbx * 10 + t.nbb;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_mfma<%d,%d,%d>", t.rw, t.mbx, t.nbb);
         switch (key) {
-            case 221: launch_mfma<2, 2, 1>(g, grid, ctx->stream); break;
-            case 222: launch_mfma<2, 2, 2>(g, grid, ctx->stream); break;
-            case 223: launch_mfma<2, 2, 3>(g, grid, ctx->stream); break;
-            case 121: launch_mfma<1, 2, 1>(g, grid, ctx->stream); break;
-            case 122: launch_mfma<1, 2, 2>(g, grid, ctx->stream); break;
-            case 123: launch_mfma<1, 2, 3>(g, grid, ctx->stream); break;
-            case 111: launch_mfma<1, 1, 1>(g, grid, ctx->stream); break;
+            case 221: launch_mfma<2, 2, 1>(g, grid, s->cur); break;
+            case 222: launch_mfma<2, 2, 2>(g, grid, s->cur); break;
+            case 223: launch_mfma<2, 2, 3>(g, grid, s->cur); break;
+            case 121: launch_mfma<1, 2, 1>(g, grid, s->cur); break;
+            case 122: launch_mfma<1, 2, 2>(g, grid, s->cur); break;
+            case 123: launch_mfma<1, 2, 3>(g, grid, s->cur); break;
+            case 111: launch_mfma<1, 1, 1>(g, grid, s->cur); break;
             default: return fail(ctx, AIPT_E_STATE, "no conv instantiation for tile %d", key);
         }
     }
-    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], ctx->stream));
+    if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], s->cur));
     // how consumers normalise dst: batch statistics from the sums this launch accumulates, or the running-statistics affine
     if (batch) dst.bn = BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)};
     else dst.bn = BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};
@@ -1389,7 +1413,8 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
     free_weights(s);
     // the carried hidden states reference the old layers' gamma/beta/statistics: a reload resets the recurrent state
     s->hidden_valid = false;
-    for (Tensor& t : s->Hid) t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
+    for (DenoiseState::ActSet& X : s->A)
+        for (Tensor& t : X.Hid) t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
     std::vector<float> f(nfl);
     memcpy(f.data(), p + off, 4 * nfl);
     const float* q = f.data();
@@ -1558,22 +1583,30 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
         return AIPT_OK;
     };
-    int rc = mk(s->In, 10, 0);
-    for (int i = 0; i < 6 && !rc; i++) {
-        const int c = i < 5 ? ENC_CH[i] : 101;
-        rc = mk(s->T1[i], c, i);
-        if (!rc) rc = mk(s->T2[i], c, i);
-        if (!rc) rc = mk(s->Hid[i], c, i);
-        if (!rc && i < 5) { rc = mk(s->P[i], c, i + 1); s->P[i].slope = 1.0f; }
-    }
-    for (int k = 1; k <= 5 && !rc; k++) {
-        rc = mk(s->D1[k], DEC_CH[k], k - 1);
-        if (!rc) rc = mk(s->D2[k], DEC_CH[k], k - 1);
+    int rc = 0;
+    for (int a = 0; a < 2 && !rc; a++) {
+        DenoiseState::ActSet& X = s->A[a];
+        rc = mk(X.In, 10, 0);
+        for (int i = 0; i < 6 && !rc; i++) {
+            const int c = i < 5 ? ENC_CH[i] : 101;
+            rc = mk(X.T1[i], c, i);
+            if (!rc) rc = mk(X.T2[i], c, i);
+            if (!rc) rc = mk(X.Hid[i], c, i);
+            if (!rc && i < 5) { rc = mk(X.P[i], c, i + 1); X.P[i].slope = 1.0f; }
+        }
+        for (int k = 1; k <= 5 && !rc; k++) {
+            rc = mk(X.D1[k], DEC_CH[k], k - 1);
+            if (!rc) rc = mk(X.D2[k], DEC_CH[k], k - 1);
+        }
     }
     if (rc) { free_activations(s); return rc; }
-    for (int k = 0; k < 2 && !rc; k++) rc = alloc(sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
+    for (int k = 0; k < DenoiseState::STAT_SETS && !rc; k++)
+        rc = alloc(sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
     if (rc) { free_activations(s); return rc; }
-    s->parity = 0;
+    for (int a = 0; a < 2; a++)
+        for (int l = 0; l < 6; l++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_level[a][l], hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_fence[k], hipEventDisableTiming));
+    s->sset = 0; s->aset = 0;
     s->H = height; s->W = width;
     s->hidden_valid = false;
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
@@ -1601,8 +1634,10 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
 
 }  // extern "C"
 
-// forward pass; the planar output is cropped to out_h x out_w (aipt_frame drops its padding here)
-int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w) {
+// forward pass; the planar output is cropped to out_h x out_w (aipt_frame drops its padding here).  pipelined: the frame runs
+// on the stream of its activation set (set 0: the context's stream, set 1: ctx->pipe) and waits, level by level, for the
+// hidden states of the frame before it; the caller forks / joins the two streams around a run of such frames.
+int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined) {
     DenoiseState* s = state(ctx);
     if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise: call aipt_denoise_configure first");
@@ -1612,61 +1647,93 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     const bool carry = (flags & AIPT_DN_HIDDEN_CARRY) != 0 && s->hidden_valid;
     const int H = s->H, W = s->W;
     int li = 0, rc = 0;
-    if (batch) {   // this frame's BN sums go to the other set: the carried hidden states still point into the last one
-        s->parity ^= 1;
-        AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->parity], 0, sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, ctx->stream));
+    const int a = s->aset ^ 1;
+    DenoiseState::ActSet& X = s->A[a];
+    DenoiseState::ActSet& prevX = s->A[a ^ 1];
+    pipelined = pipelined && ctx->pipe;
+    hipStream_t st = pipelined && a == 1 ? ctx->pipe : ctx->stream;
+    hipStream_t other = a == 1 ? ctx->stream : ctx->pipe;
+    s->cur = st;
+    s->aset = a;
+    // a forward pass whose launches are being timed (aipt_denoise_profile_*) runs alone: the other stream drains before it
+    // and resumes after it, so that an event pair brackets one kernel and not its overlap with the other frame's
+    const bool timed = pipelined && s->prof_mask && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
+    if (timed) {
+        AIPT_HIP(ctx, hipEventRecord(s->ev_fence[0], other));
+        AIPT_HIP(ctx, hipStreamWaitEvent(st, s->ev_fence[0], 0));
     }
+    if (batch) {   // this frame's BN sums go to the next set of the ring: the carried hidden states still point into the last one
+        s->sset = (s->sset + 1) % DenoiseState::STAT_SETS;
+        AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->sset], 0, sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, st));
+    }
+    // level l of this frame reads the hidden state the previous frame wrote at level l (on the other stream when pipelined)
+    auto wait_hidden = [&](int l) -> hipError_t {
+        if (pipelined && carry && s->ev_level_valid[a ^ 1][l]) return hipStreamWaitEvent(st, s->ev_level[a ^ 1][l], 0);
+        return hipSuccess;
+    };
+    auto hidden_written = [&](int l) -> hipError_t {
+        s->ev_level_valid[a][l] = pipelined;
+        return pipelined ? hipEventRecord(s->ev_level[a][l], st) : hipSuccess;
+    };
     Tensor in;
     // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94).  The split-fp16 conv reads it as it is; the other
     // implementations get a C4 copy first.
-    in = s->In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
+    in = X.In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
     const bool direct = impl_is_f16(s->impl) && (long)H * W >= f16_min_pixels();
     if (direct) {
         in.p = const_cast<float*>(d_in10); in.planar = 1;
     } else {
         const size_t hw = (size_t)H * W, n = (size_t)pad4(10) * hw;
         const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-        hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, ctx->stream, d_in10, 10, hw, s->In.p);
+        hipLaunchKernelGGL(planar_to_c4, dim3(grid), dim3(256), 0, st, d_in10, 10, hw, X.In.p);
     }
     const Tensor* x = &in;
     // encoders: out1 = LReLU(BN(conv(X))); out2 = LReLU(BN(conv(BN(LReLU(conv(cat(out1, hidden))))))); then MaxPool
     for (int i = 0; i < 5; i++) {
         const int h = H >> i, w = W >> i;
-        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, s->T1[i], batch, false))) return rc;
-        if ((rc = run_conv(ctx, s, li++, s->T1[i], 0, &s->Hid[i], 0, h, w, 1, s->T2[i], batch, carry))) return rc;
-        Tensor t2 = s->T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
-        if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, s->Hid[i], batch, false))) return rc;
-        s->Hid[i].slope = SLOPE;
+        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, X.T1[i], batch, false))) return rc;
+        AIPT_HIP(ctx, wait_hidden(i));
+        if ((rc = run_conv(ctx, s, li++, X.T1[i], 0, &prevX.Hid[i], 0, h, w, 1, X.T2[i], batch, carry))) return rc;
+        Tensor t2 = X.T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
+        if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, X.Hid[i], batch, false))) return rc;
+        X.Hid[i].slope = SLOPE;
+        AIPT_HIP(ctx, hidden_written(i));
         const size_t n = (size_t)(h / 2) * (w / 2);                         // one thread per pooled pixel of a channel quad
         const int quads = pad4(ENC_CH[i]) / 4;
         int grid = (int)((n + 255) / 256);
         if (grid * quads > 4096) grid = (4096 + quads - 1) / quads;
-        hipLaunchKernelGGL(pool2_norm, dim3(grid, quads), dim3(256), 0, ctx->stream, s->Hid[i].p, s->Hid[i].bn, SLOPE,
-                           ENC_CH[i], h, w, s->P[i].p);
-        x = &s->P[i];
+        hipLaunchKernelGGL(pool2_norm, dim3(grid, quads), dim3(256), 0, st, X.Hid[i].p, X.Hid[i].bn, SLOPE,
+                           ENC_CH[i], h, w, X.P[i].p);
+        x = &X.P[i];
     }
     {   // bottleneck: conv-BN-LReLU three times
         const int h = H >> 5, w = W >> 5;
-        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, s->T1[5], batch, false))) return rc;
-        if ((rc = run_conv(ctx, s, li++, s->T1[5], 0, &s->Hid[5], 0, h, w, 0, s->T2[5], batch, carry))) return rc;
-        if ((rc = run_conv(ctx, s, li++, s->T2[5], 0, nullptr, 0, h, w, 0, s->Hid[5], batch, false))) return rc;
-        s->Hid[5].slope = SLOPE;
+        if ((rc = run_conv(ctx, s, li++, *x, 0, nullptr, 0, h, w, 0, X.T1[5], batch, false))) return rc;
+        AIPT_HIP(ctx, wait_hidden(5));
+        if ((rc = run_conv(ctx, s, li++, X.T1[5], 0, &prevX.Hid[5], 0, h, w, 0, X.T2[5], batch, carry))) return rc;
+        if ((rc = run_conv(ctx, s, li++, X.T2[5], 0, nullptr, 0, h, w, 0, X.Hid[5], batch, false))) return rc;
+        X.Hid[5].slope = SLOPE;
+        AIPT_HIP(ctx, hidden_written(5));
     }
     // decoders: cat(prev, skip) -> Upsample x2 -> conv BN LReLU conv BN LReLU
-    const Tensor* prev = &s->Hid[5];
+    const Tensor* prev = &X.Hid[5];
     for (int k = 5; k >= 1; k--) {
         const int h = H >> (k - 1), w = W >> (k - 1);
-        if ((rc = run_conv(ctx, s, li++, *prev, 1, &s->P[k - 1], 1, h, w, 0, s->D1[k], batch, true))) return rc;
-        if ((rc = run_conv(ctx, s, li++, s->D1[k], 0, nullptr, 0, h, w, 0, s->D2[k], batch, false))) return rc;
-        prev = &s->D2[k];
+        if ((rc = run_conv(ctx, s, li++, *prev, 1, &X.P[k - 1], 1, h, w, 0, X.D1[k], batch, true))) return rc;
+        if ((rc = run_conv(ctx, s, li++, X.D1[k], 0, nullptr, 0, h, w, 0, X.D2[k], batch, false))) return rc;
+        prev = &X.D2[k];
     }
     {
         const size_t n = (size_t)out_h * out_w;
         const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-        hipLaunchKernelGGL(apply_norm, dim3(grid, 1), dim3(256), 0, ctx->stream, s->D2[1].p, s->D2[1].bn, SLOPE, 3, H, W,
+        hipLaunchKernelGGL(apply_norm, dim3(grid, 1), dim3(256), 0, st, X.D2[1].p, X.D2[1].bn, SLOPE, 3, H, W,
                            d_out3, out_h, out_w);
     }
     AIPT_HIP(ctx, hipGetLastError());
+    if (timed) {
+        AIPT_HIP(ctx, hipEventRecord(s->ev_fence[1], st));
+        AIPT_HIP(ctx, hipStreamWaitEvent(other, s->ev_fence[1], 0));
+    }
     s->hidden_valid = true;
     if (s->prof_mask) {
         if (s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0) s->prof_calls++;
@@ -1750,7 +1817,7 @@ int aipt_denoise_get_hidden(aipt_ctx* ctx, int level, float* d_dst) {
     DenoiseState* s = state(ctx);
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise_get_hidden: not configured");
     if (level < 0 || level > 5 || !d_dst) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_get_hidden: level %d", level);
-    const Tensor& t = s->Hid[level];
+    const Tensor& t = s->A[s->aset].Hid[level];
     const size_t hw = (size_t)(s->H >> level) * (s->W >> level);
     if (!s->hidden_valid) {
         AIPT_HIP(ctx, hipMemsetAsync(d_dst, 0, sizeof(float) * t.C * hw, ctx->stream));
@@ -1768,12 +1835,12 @@ int aipt_denoise_set_hidden(aipt_ctx* ctx, int level, const float* d_src) {
     DenoiseState* s = state(ctx);
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise_set_hidden: not configured");
     if (level < 0 || level > 5 || !d_src) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_hidden: level %d", level);
-    Tensor& t = s->Hid[level];
+    Tensor& t = s->A[s->aset].Hid[level];
     const size_t hw = (size_t)(s->H >> level) * (s->W >> level);
     if (!s->hidden_valid) {
         // the other levels must read as zeros: raw 0 with identity transform
         for (int l = 0; l < 6; l++) {
-            Tensor& o = s->Hid[l];
+            Tensor& o = s->A[s->aset].Hid[l];
             AIPT_HIP(ctx, hipMemsetAsync(o.p, 0, sizeof(float) * pad4(o.C) * (size_t)(s->H >> l) * (s->W >> l), ctx->stream));
             o.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
             o.slope = 1.0f;

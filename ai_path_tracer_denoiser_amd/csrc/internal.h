@@ -36,6 +36,9 @@ struct aipt_ctx {
     int front = 0;
     // aipt_frame_prefetch: the next frame's trace runs on `side` into the back G-buffer while this frame is denoised
     hipStream_t side = nullptr;
+    // aipt_frames: the denoiser passes of consecutive frames alternate between `stream` and `pipe` (denoise_run, pipelined)
+    hipStream_t pipe = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_denoised[2] = {nullptr, nullptr};   // last denoise that read d_gbufs[i] has finished
     hipEvent_t ev_prefetched = nullptr;               // the prefetched trace has finished
     hipEvent_t ev_traced = nullptr;                   // last trace (any stream) has finished: traces share one path state
@@ -98,10 +101,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
 inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
+    if (e == hipSuccess && ctx->pipe) e = hipStreamSynchronize(ctx->pipe);
     return e;
 }
 // aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)
-int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w);
+int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined = false);
 void trace_destroy(aipt_ctx* ctx);
 void denoise_destroy(aipt_ctx* ctx);
 

@@ -67,7 +67,8 @@ def parse_args():
                     help="conv arithmetic: f32-input MFMA (exact fp32 chain), split-fp16 MFMA (default), or split-fp16 activations x fp16 weights")
     ap.add_argument("--batch", type=int, default=None,
                     help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
-                         "1 = frame by frame, aipt_frame).  Default: 8 on mesh scenes, 1 without a mesh")
+                         "1 = frame by frame, aipt_frame) and run the denoiser passes of consecutive frames on two streams, "
+                         "level by level behind each other.  Default: 8")
     ap.add_argument("--prefetch", action="store_true",
                     help="also trace the next batch (frame) on a low-priority second stream during the denoiser passes of this "
                          "one (+9 %% on configs[2], but the streams' kernels fight for CUs on the reflective scene: off by default)")
@@ -86,7 +87,7 @@ def parse_args():
     args.mesh_kind = args.mesh_kind or kind or "atrium"
     args.impl = args.impl or impl
     if args.batch is None:
-        args.batch = 8 if args.mesh else 1
+        args.batch = 8
     return args
 
 
@@ -256,14 +257,16 @@ def main():
     barrier()
 
     # ---- timed region: exactly K frames
-    # HIP-event pairs around the launches of the dominant conv kernel and of the bounce kernel, on the launch stream, on every
-    # 4th frame of the timed region (each pair costs the stream ~2 us; all frames would cost 4 % of `value`)
-    PROF_EVERY = 4
+    # HIP-event pairs around the launches of the dominant conv kernel and of the bounce kernel, on the launch stream, on the
+    # first frame of every third batch of the timed region (frame by frame: every 4th frame).  The library runs a timed forward pass ALONE (the
+    # other denoiser stream drains before it and resumes after it), so a pair brackets the kernel and not its overlap with
+    # the next frame's launches; that costs the first two frames of every third batch their overlap (~2 % of `value`).
+    PROF_EVERY = 3 * B if B >= 4 else 4
     if prof_layers:
         nrec = (args.steps + PROF_EVERY - 1) // PROF_EVERY
         ctx.profile_stride(PROF_EVERY)
         ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
-        ctx.trace_profile_begin(nrec, PROF_EVERY if B == 1 else 1)
+        ctx.trace_profile_begin(nrec if B == 1 else (args.steps + B - 1) // B + 1, PROF_EVERY if B == 1 else 1)
     barrier()
     t0 = time.perf_counter()
     run_frames(args.warmup, per_rank)
@@ -276,6 +279,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n_live = ctx.live_counts(depth)            # of the last trace call (all frames of the last batch together)
+    trace_kernels = [ctx.trace_kernel_name(0), ctx.trace_kernel_name(1)] if depth > 1 else [ctx.trace_kernel_name(0)] * 2
     # the trace / denoise split: one un-pipelined frame, after the timed region
     ctx.sync()
     ctx.frame_set_timing(True)
@@ -340,7 +344,7 @@ def main():
             by_late = sum(nb[b] * 160.0 for b in late) * fpc                # N_b x 160 B per bounce
             t_first = float(tr_ms[0]) / tr_calls
             by_first = (nb[0] * 160.0 + nb[0] * 64.0) * fpc                 # + G-buffer write and image RMW, once per frame
-            name = ctx.trace_kernel_name(1)
+            name = trace_kernels[1]
             g_late = by_late / (t_late * 1e-3) / 1e9 if t_late > 0 else 0.0
             tr_roof = {"bound": "hbm", "achieved": round(g_late, 1), "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
                        "frac": round(g_late * 1e9 / MI355X_HBM_BPS, 5), "traffic": pmc_traffic(name),
@@ -349,7 +353,7 @@ def main():
                        "algorithmic_bytes_per_launch": by_late / len(late),
                        "byte_model": "SURVEY 8d: sum over bounces of N_b x 160 B (44 B state read + 44 B write, 36 B hit record "
                                      "write + read of the reference's layout); BVH and triangle fetches are overhead, not algorithmic",
-                       "first_bounce": {"kernel": ctx.trace_kernel_name(0), "avg_launch_ms": round(t_first, 5),
+                       "first_bounce": {"kernel": trace_kernels[0], "avg_launch_ms": round(t_first, 5),
                                         "algorithmic_bytes_per_launch": by_first,
                                         "achieved_GBps": round(by_first / (t_first * 1e-3) / 1e9, 1) if t_first > 0 else 0.0},
                        "rays_per_frame": int(sum(nb)), "grays_per_s": round(sum(nb) * fpc / ((t_late + t_first) * 1e-3) / 1e9, 3),
@@ -388,7 +392,8 @@ def main():
                                    f"BN {args.bn}-stats, hidden {args.hidden}, conv {args.impl}",
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
-                       "pipelining": ((f"traces of {B} consecutive frames share their launches (aipt_frames)" if B > 1 else "frame by frame")
+                       "pipelining": ((f"traces of {B} consecutive frames share their launches and their denoiser passes run on two "
+                                       f"streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else "frame by frame")
                                       + ("; the next batch is traced on a second stream during the denoiser passes" if args.prefetch else "")
                                       + "; frames bit-identical to un-pipelined rendering")},
             "roofline": roof,

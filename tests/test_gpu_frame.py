@@ -205,3 +205,42 @@ def test_frame_batches_equal_the_frame_by_frame_sequence():
         assert len(got) == len(ref)
         for k in range(len(ref)):
             assert np.array_equal(got[k], ref[k]), (batch, pf, k)
+
+
+@pytest.mark.parametrize("bn_batch,carry", [(True, True), (True, False), (False, True)])
+def test_pipelined_denoiser_passes_equal_the_sequential_ones(bn_batch, carry):
+    """aipt_frames runs the denoiser passes of consecutive frames on two streams, frame n+1 one encoder level behind frame n
+    (two activation sets, a ring of BN-sum sets, per-level events).  Three batches of 8 at a size where the launches of two
+    frames really overlap must give the bits of the frame-by-frame sequence, in every BN x hidden mode."""
+    import torch
+    W, H, depth = 320, 192, 3
+    sc = api.Scene(CORNELL, res=(W, H), depth=depth)
+    cams = [sc.orbit(phi=sc.phi + 0.05 * k) for k in range(21)]
+    blob = synth.make_blob(11)
+
+    def run(batch):
+        ctx = api.Context(0)
+        ctx.pathtrace_init_scene(sc, W, H)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        outs = []
+        if batch == 1:
+            o = torch.empty(3, H, W, device="cuda")
+            for k, c in enumerate(cams):
+                ctx.frame(c, 1, depth, o, bn_batch=bn_batch, carry=carry and k > 0)
+                ctx.sync()
+                outs.append(o.cpu().numpy().copy())
+        else:
+            ctx.frames_configure(batch)
+            ob = [torch.empty(3, H, W, device="cuda") for _ in range(batch)]
+            for k in range(0, len(cams), batch):
+                nb = min(batch, len(cams) - k)
+                ctx.frames(cams[k:k + nb], 1, depth, ob, bn_batch=bn_batch, carry_first=carry and k > 0, carry=carry)
+                ctx.sync()
+                outs += [ob[j].cpu().numpy().copy() for j in range(nb)]
+        ctx.close()
+        return outs
+    ref = run(1)
+    got = run(8)
+    for k in range(len(ref)):
+        assert np.array_equal(got[k], ref[k]), (bn_batch, carry, k)

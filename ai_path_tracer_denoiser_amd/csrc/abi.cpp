@@ -77,9 +77,9 @@ void aipt_destroy(aipt_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
-    if (ctx->pipe) { hipStreamSynchronize(ctx->pipe); hipStreamDestroy(ctx->pipe); }
+    for (hipStream_t ps : ctx->pipe) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    for (hipEvent_t ev : ctx->ev_join) if (ev) hipEventDestroy(ev);
     aipt::trace_destroy(ctx);
     aipt::denoise_destroy(ctx);
     for (float* g : ctx->d_gbufs) if (g) hipFree(g);
@@ -305,26 +305,30 @@ int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, i
     }
     ctx->d_gbatch = ctx->d_gbatches[ctx->bfront];
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
-    // the frames' denoiser passes alternate between two streams, each frame following the one before it level by level
+    // the frames' denoiser passes rotate over AIPT_DN_PIPE streams, each frame following the one before it level by level
     // (denoise_run): fork after the trace, join before anything that follows on the context's stream
     static const bool pipe_env = !getenv("AIPT_DN_PIPELINE") || atoi(getenv("AIPT_DN_PIPELINE")) != 0;
     const bool pipelined = pipe_env && nframes > 1;
     if (pipelined) {
-        if (!ctx->pipe) {
-            AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe, hipStreamNonBlocking));
+        if (!ctx->ev_fork) {
+            for (int k = 0; k < AIPT_DN_PIPE - 1; k++) {
+                AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->pipe[k], hipStreamNonBlocking));
+                AIPT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[k], hipEventDisableTiming));
+            }
             AIPT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            AIPT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
         AIPT_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        AIPT_HIP(ctx, hipStreamWaitEvent(ctx->pipe, ctx->ev_fork, 0));
+        for (hipStream_t ps : ctx->pipe) AIPT_HIP(ctx, hipStreamWaitEvent(ps, ctx->ev_fork, 0));
     }
     for (int j = 0; j < nframes; j++) {
         rc = aipt::denoise_run(ctx, ctx->d_gbatch + j * frame, d_out3[j], j == 0 ? dn_flags_first : dn_flags_rest, ctx->fh, ctx->fw, pipelined);
         if (rc) return rc;
     }
     if (pipelined) {
-        AIPT_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->pipe));
-        AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        for (int k = 0; k < AIPT_DN_PIPE - 1; k++) {
+            AIPT_HIP(ctx, hipEventRecord(ctx->ev_join[k], ctx->pipe[k]));
+            AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[k], 0));
+        }
     }
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_bdenoised[ctx->bfront], ctx->stream));
     ctx->bdenoised_valid[ctx->bfront] = true;

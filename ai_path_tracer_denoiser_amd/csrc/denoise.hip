@@ -1099,30 +1099,32 @@ struct DenoiseState {
     bool have_weights = false;
     LayerW L[NLAYERS];
     int H = 0, W = 0;
-    // Two activation sets, alternating by frame: frame n works in A[n & 1] and reads the hidden states frame n-1 left in the
-    // other set.  That is what lets aipt_frames run consecutive frames of ONE recurrent sequence on two streams (below).
+    // NSET activation sets, rotating by frame: frame n works in A[n % NSET] and reads the hidden states frame n-1 left in
+    // the set before it.  That is what lets aipt_frames run consecutive frames of ONE recurrent sequence on NSET streams.
     struct ActSet {
         Tensor In;                     // C4 copy of the planar network input
         Tensor T1[6], T2[6], Hid[6];   // per level 0..5 (5 = bottleneck)
         Tensor P[5];                   // pooled, normalised encoder outputs (identity transform)
         Tensor D1[6], D2[6];           // decoder k = 1..5
-    } A[2];
+    } A[AIPT_DN_PIPE];
+    static constexpr int NSET = AIPT_DN_PIPE;
     int aset = 0;                      // set of the last frame (its Hid[] are the carried hidden states)
-    // BN sums of every conv layer, one set per frame in a ring of four: the hidden states written in frame n are read in
-    // frame n+1, whose own sums go to the next set (one memset per frame instead of a finalize launch per conv); with two
-    // frames in flight the set zeroed for frame n was last read by frame n-3, which the stream order has retired.
+    // BN sums of every conv layer, one set per frame in a ring of 2 x NSET: the hidden states written in frame n are read in
+    // frame n+1, whose own sums go to the next set (one memset per frame instead of a finalize launch per conv); the set
+    // zeroed for frame n belonged to frame n - 2 NSET (same stream: retired) and was last read, as hidden-state statistics,
+    // by frame n - 2 NSET + 1, whose bottleneck the frames in between have waited for.
     static constexpr int STAT_SC = 128;                                    // channel stride (>= every cout)
     static constexpr size_t STAT_LAYER = (size_t)NSLOT * STAT_SC * 2;      // doubles per layer
-    static constexpr int STAT_SETS = 4;
-    double* stat[STAT_SETS] = {nullptr, nullptr, nullptr, nullptr};
+    static constexpr int STAT_SETS = 2 * AIPT_DN_PIPE;
+    double* stat[STAT_SETS] = {};
     int sset = 0;
     // Frame pipelining (aipt_frames): frame n+1 may enter encoder level L as soon as frame n has left it (its hidden state of
-    // that level is complete), so the launches of two frames interleave on two streams and the many small launches of the
-    // deep levels and the decoder of one frame (a few dozen workgroups on 256 CUs) run beside the full-size layers of the other.
+    // that level is complete), so the launches of NSET frames interleave on NSET streams and the many small launches of the
+    // deep levels and the decoder of one frame (a few dozen workgroups on 256 CUs) run beside the full-size layers of another.
     hipStream_t cur = nullptr;         // stream of the forward pass being enqueued
-    hipEvent_t ev_level[2][6] = {};    // [set][level]: the hidden state of that level is written
-    hipEvent_t ev_fence[2] = {};       // around a timed forward pass
-    bool ev_level_valid[2][6] = {};
+    hipEvent_t ev_level[AIPT_DN_PIPE][6] = {};    // [set][level]: the hidden state of that level is written
+    hipEvent_t ev_fence[AIPT_DN_PIPE] = {};       // around a timed forward pass: [k < NSET-1] drain of the other streams, [NSET-1] its end
+    bool ev_level_valid[AIPT_DN_PIPE][6] = {};
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
     int num_cus = 256;
@@ -1190,13 +1192,13 @@ static void free_activations(DenoiseState* s) {
     for (void* p : s->allocs) hipFree(p);
     s->allocs.clear();
     for (int k = 0; k < DenoiseState::STAT_SETS; k++) s->stat[k] = nullptr;
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < DenoiseState::NSET; a++)
         for (int l = 0; l < 6; l++) {
             if (s->ev_level[a][l]) hipEventDestroy(s->ev_level[a][l]);
             s->ev_level[a][l] = nullptr;
             s->ev_level_valid[a][l] = false;
         }
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < DenoiseState::NSET; k++) {
         if (s->ev_fence[k]) hipEventDestroy(s->ev_fence[k]);
         s->ev_fence[k] = nullptr;
     }
@@ -1584,7 +1586,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
         return AIPT_OK;
     };
     int rc = 0;
-    for (int a = 0; a < 2 && !rc; a++) {
+    for (int a = 0; a < DenoiseState::NSET && !rc; a++) {
         DenoiseState::ActSet& X = s->A[a];
         rc = mk(X.In, 10, 0);
         for (int i = 0; i < 6 && !rc; i++) {
@@ -1603,9 +1605,9 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     for (int k = 0; k < DenoiseState::STAT_SETS && !rc; k++)
         rc = alloc(sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
     if (rc) { free_activations(s); return rc; }
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < DenoiseState::NSET; a++)
         for (int l = 0; l < 6; l++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_level[a][l], hipEventDisableTiming));
-    for (int k = 0; k < 2; k++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_fence[k], hipEventDisableTiming));
+    for (int k = 0; k < DenoiseState::NSET; k++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_fence[k], hipEventDisableTiming));
     s->sset = 0; s->aset = 0;
     s->H = height; s->W = width;
     s->hidden_valid = false;
@@ -1635,8 +1637,8 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
 }  // extern "C"
 
 // forward pass; the planar output is cropped to out_h x out_w (aipt_frame drops its padding here).  pipelined: the frame runs
-// on the stream of its activation set (set 0: the context's stream, set 1: ctx->pipe) and waits, level by level, for the
-// hidden states of the frame before it; the caller forks / joins the two streams around a run of such frames.
+// on the stream of its activation set (set 0: the context's stream, set k: ctx->pipe[k-1]) and waits, level by level, for the
+// hidden states of the frame before it; the caller forks / joins the streams around a run of such frames.
 int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined) {
     DenoiseState* s = state(ctx);
     if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
@@ -1647,20 +1649,23 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     const bool carry = (flags & AIPT_DN_HIDDEN_CARRY) != 0 && s->hidden_valid;
     const int H = s->H, W = s->W;
     int li = 0, rc = 0;
-    const int a = s->aset ^ 1;
+    constexpr int NSET = DenoiseState::NSET;
+    const int a = (s->aset + 1) % NSET, ap = s->aset;          // this frame's set; the previous frame's
     DenoiseState::ActSet& X = s->A[a];
-    DenoiseState::ActSet& prevX = s->A[a ^ 1];
-    pipelined = pipelined && ctx->pipe;
-    hipStream_t st = pipelined && a == 1 ? ctx->pipe : ctx->stream;
-    hipStream_t other = a == 1 ? ctx->stream : ctx->pipe;
+    DenoiseState::ActSet& prevX = s->A[ap];
+    pipelined = pipelined && ctx->ev_fork;
+    auto stream_of = [&](int set) { return set == 0 ? ctx->stream : ctx->pipe[set - 1]; };
+    hipStream_t st = pipelined ? stream_of(a) : ctx->stream;
     s->cur = st;
     s->aset = a;
-    // a forward pass whose launches are being timed (aipt_denoise_profile_*) runs alone: the other stream drains before it
-    // and resumes after it, so that an event pair brackets one kernel and not its overlap with the other frame's
+    // a forward pass whose launches are being timed (aipt_denoise_profile_*) runs alone: the other streams drain before it
+    // and resume after it, so that an event pair brackets one kernel and not its overlap with another frame's
     const bool timed = pipelined && s->prof_mask && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     if (timed) {
-        AIPT_HIP(ctx, hipEventRecord(s->ev_fence[0], other));
-        AIPT_HIP(ctx, hipStreamWaitEvent(st, s->ev_fence[0], 0));
+        for (int k = 1; k < NSET; k++) {
+            AIPT_HIP(ctx, hipEventRecord(s->ev_fence[k - 1], stream_of((a + k) % NSET)));
+            AIPT_HIP(ctx, hipStreamWaitEvent(st, s->ev_fence[k - 1], 0));
+        }
     }
     if (batch) {   // this frame's BN sums go to the next set of the ring: the carried hidden states still point into the last one
         s->sset = (s->sset + 1) % DenoiseState::STAT_SETS;
@@ -1668,7 +1673,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     }
     // level l of this frame reads the hidden state the previous frame wrote at level l (on the other stream when pipelined)
     auto wait_hidden = [&](int l) -> hipError_t {
-        if (pipelined && carry && s->ev_level_valid[a ^ 1][l]) return hipStreamWaitEvent(st, s->ev_level[a ^ 1][l], 0);
+        if (pipelined && carry && s->ev_level_valid[ap][l]) return hipStreamWaitEvent(st, s->ev_level[ap][l], 0);
         return hipSuccess;
     };
     auto hidden_written = [&](int l) -> hipError_t {
@@ -1731,8 +1736,8 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     }
     AIPT_HIP(ctx, hipGetLastError());
     if (timed) {
-        AIPT_HIP(ctx, hipEventRecord(s->ev_fence[1], st));
-        AIPT_HIP(ctx, hipStreamWaitEvent(other, s->ev_fence[1], 0));
+        AIPT_HIP(ctx, hipEventRecord(s->ev_fence[NSET - 1], st));
+        for (int k = 1; k < NSET; k++) AIPT_HIP(ctx, hipStreamWaitEvent(stream_of((a + k) % NSET), s->ev_fence[NSET - 1], 0));
     }
     s->hidden_valid = true;
     if (s->prof_mask) {

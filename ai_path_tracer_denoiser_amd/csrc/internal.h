@@ -18,6 +18,10 @@ struct DenoiseState;   // denoise.hip
 
 }  // namespace aipt
 
+// frames of one recurrent sequence whose denoiser passes are in flight together (independent sequences: 2 streams 1.25x, 3 streams 1.38x,
+// 4 streams 1.37x the throughput of one, tools/overlap_probe.py; ONE sequence, level by level behind each other: 3 in flight = 2 in flight)
+constexpr int AIPT_DN_PIPE = 2;
+
 struct aipt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -36,9 +40,10 @@ struct aipt_ctx {
     int front = 0;
     // aipt_frame_prefetch: the next frame's trace runs on `side` into the back G-buffer while this frame is denoised
     hipStream_t side = nullptr;
-    // aipt_frames: the denoiser passes of consecutive frames alternate between `stream` and `pipe` (denoise_run, pipelined)
-    hipStream_t pipe = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
+    // pipelined): AIPT_DN_PIPE frames in flight
+    hipStream_t pipe[AIPT_DN_PIPE - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[AIPT_DN_PIPE - 1] = {};
     hipEvent_t ev_denoised[2] = {nullptr, nullptr};   // last denoise that read d_gbufs[i] has finished
     hipEvent_t ev_prefetched = nullptr;               // the prefetched trace has finished
     hipEvent_t ev_traced = nullptr;                   // last trace (any stream) has finished: traces share one path state
@@ -101,7 +106,8 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
 inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
-    if (e == hipSuccess && ctx->pipe) e = hipStreamSynchronize(ctx->pipe);
+    for (hipStream_t ps : ctx->pipe)
+        if (e == hipSuccess && ps) e = hipStreamSynchronize(ps);
     return e;
 }
 // aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)

@@ -30,6 +30,12 @@ import subprocess
 import sys
 import time
 
+# idle OpenMP threads sleep instead of spinning: the CPU oracle's pool and torch's CPU pool (cpu_baseline / smoke) share this
+# process, and two pools of busy-waiting threads starve each other (tests/conftest.py)
+if os.path.exists("/dev/kfd"):
+    for _k, _v in (("OMP_WAIT_POLICY", "PASSIVE"), ("GOMP_SPINCOUNT", "0"), ("KMP_BLOCKTIME", "0")):
+        os.environ.setdefault(_k, _v)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

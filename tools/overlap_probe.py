@@ -15,7 +15,8 @@ def main():
     H, W = 736, 1280
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     blob = synth.make_blob(1)
-    ctxs = [api.Context(0) for _ in range(2)]
+    nctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    ctxs = [api.Context(0) for _ in range(nctx)]
     xs, ys = [], []
     for c in ctxs:
         c.denoise_configure(H, W)
@@ -35,10 +36,10 @@ def main():
             c.sync()
         return (time.perf_counter() - t0) / (frames * len(which))
 
-    run([0, 1], 10)
+    run(list(range(nctx)), 10)
     one = run([0], n)
-    two = run([0, 1], n)
-    print(f"one stream: {one * 1e3:.3f} ms per denoise; two streams interleaved: {two * 1e3:.3f} ms per denoise "
+    two = run(list(range(nctx)), n)
+    print(f"one stream: {one * 1e3:.3f} ms per denoise; {nctx} streams interleaved: {two * 1e3:.3f} ms per denoise "
           f"({one / two:.2f}x throughput)")
 
 

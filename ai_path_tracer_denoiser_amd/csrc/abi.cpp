@@ -261,10 +261,10 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
 int aipt_frames_configure(aipt_ctx* ctx, int batch) {
     AIPT_CHECK_CTX(ctx);
     if (!ctx->d_gbuf) return fail(ctx, AIPT_E_STATE, "aipt_frames_configure: call aipt_frame_configure first");
-    if (batch < 1 || batch > 8) return fail(ctx, AIPT_E_INVALID, "aipt_frames_configure: batch %d (1..8)", batch);
+    if (batch < 1 || batch > AIPT_FRAMES_MAX) return fail(ctx, AIPT_E_INVALID, "aipt_frames_configure: batch %d (1..%d)", batch, AIPT_FRAMES_MAX);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
-    const int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch);
+    const int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch < AIPT_TRACE_BATCH_MAX ? batch : AIPT_TRACE_BATCH_MAX);
     if (rc) return rc;
     for (float*& g : ctx->d_gbatches) if (g) { hipFree(g); g = nullptr; }
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
@@ -279,6 +279,19 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch) {
     ctx->bdenoised_valid[0] = ctx->bdenoised_valid[1] = false; ctx->bpf.valid = false;
     ctx->fbatch = batch;
     ctx->pf.valid = false;
+    return AIPT_OK;
+}
+
+// the traces of a batch of frames: one set of launches per AIPT_TRACE_BATCH_MAX frames (the trace's cameras travel as kernel
+// arguments), one after the other on `st`, into consecutive G-buffers
+static int trace_frames(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
+                        float* d_gbatch) {
+    const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
+    for (int k = 0; k < nframes; k += AIPT_TRACE_BATCH_MAX) {
+        const int nb = nframes - k < AIPT_TRACE_BATCH_MAX ? nframes - k : AIPT_TRACE_BATCH_MAX;
+        const int rc = aipt::trace_on_stream(ctx, st, cams + k, nb, iter, depth, trace_flags, d_gbatch + k * frame, ctx->fhp, ctx->fwp, frame);
+        if (rc) return rc;
+    }
     return AIPT_OK;
 }
 
@@ -300,7 +313,7 @@ int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, i
         ctx->bfront = ctx->bpf.buf;
         AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_prefetched, 0));
     } else {
-        rc = aipt::trace_on_stream(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[ctx->bfront], ctx->fhp, ctx->fwp, frame);
+        rc = trace_frames(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[ctx->bfront]);
         if (rc) return rc;
     }
     ctx->d_gbatch = ctx->d_gbatches[ctx->bfront];
@@ -308,7 +321,9 @@ int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, i
     // the frames' denoiser passes rotate over AIPT_DN_PIPE streams, each frame following the one before it level by level
     // (denoise_run): fork after the trace, join before anything that follows on the context's stream
     static const bool pipe_env = !getenv("AIPT_DN_PIPELINE") || atoi(getenv("AIPT_DN_PIPELINE")) != 0;
-    const bool pipelined = pipe_env && nframes > 1;
+    // (not together with aipt_frames_prefetch: a third, low-priority stream of trace launches beside the two denoiser
+    // streams collapsed to 52 frames/s on configs[2])
+    const bool pipelined = pipe_env && nframes > 1 && !ctx->side;
     if (pipelined) {
         if (!ctx->ev_fork) {
             for (int k = 0; k < AIPT_DN_PIPE - 1; k++) {
@@ -351,8 +366,7 @@ int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, in
     const int back = ctx->bfront ^ 1;
     // the denoiser passes that last read the back G-buffers must be done before the trace overwrites them
     if (ctx->bdenoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_bdenoised[back], 0));
-    const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
-    const int rc = aipt::trace_on_stream(ctx, ctx->side, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back], ctx->fhp, ctx->fwp, frame);
+    const int rc = trace_frames(ctx, ctx->side, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back]);
     if (rc) return rc;
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
     ctx->bpf.valid = true; ctx->bpf.cams.assign(cams, cams + nframes); ctx->bpf.iter = iter; ctx->bpf.depth = depth;

@@ -18,7 +18,8 @@
 // ranks' GPUs with RCCL (aipt_comm_*), nothing is exchanged per frame.  --ranks R > N puts several ranks on a GPU and
 // replaces RCCL by an in-process copy shim, so a one-GPU box can check that sharded rendering is byte-identical
 // (tests/test_cli.py); --reset-every C makes a single rank drop the hidden state where R ranks would (every C frames).
-// --batch B traces B consecutive frames with one set of launches (aipt_frames; identical results).
+// --batch B (<= 32) traces B consecutive frames with one set of launches per 8 and pipelines their denoiser passes over two
+// streams (aipt_frames; identical results).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -330,7 +331,7 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "aiptd: unknown option %s\n", a.c_str()); return 1; }
     }
     if (o.ranks <= 0) o.ranks = o.gpus;
-    if (o.gpus < 1 || o.ranks < o.gpus || o.batch < 1 || o.batch > 8) { fprintf(stderr, "aiptd: bad --gpus/--ranks/--batch\n"); return 1; }
+    if (o.gpus < 1 || o.ranks < o.gpus || o.batch < 1 || o.batch > 32) { fprintf(stderr, "aiptd: bad --gpus/--ranks/--batch\n"); return 1; }
     crc_init();
 
     std::vector<unsigned char> blob;

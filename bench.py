@@ -13,11 +13,13 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     node has fewer GPUs); under torch.distributed.run: one rank per GPU, frames are sharded in contiguous chunks, rank 0
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
-Frame batches (results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): on mesh scenes the traces of 8
-consecutive frames share one set of bounce launches (a single 1280x720 frame leaves most of the chip idle in its later bounces:
-every launch lasts as long as its slowest wave's chain of dependent BVH fetches; the frames are interleaved pixel by pixel,
-so neighbouring lanes walk near-identical paths); the eight denoiser passes follow in order with the hidden state carried.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is measured on
-one single frame after the timed region.
+Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds 32
+consecutive frames.  Their traces share one set of bounce launches per 8 frames (a single 1280x720 frame leaves most of the
+chip idle in its later bounces; the frames are interleaved pixel by pixel and a workgroup pools the BVH walks of 1024 paths,
+refilling idle lanes).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
+it, so the many small launches of one frame's deep levels run beside the full-size layers of the other; the hidden state is
+carried through the batch.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is
+measured on one single frame after the timed region.
 
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the kernel that dominates THIS workload (HIP events on the
 launch stream inside the timed region; the runner-up kernel under "roofline_other"), "cpu_baseline" (the CPU oracle timed
@@ -74,10 +76,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None,
                     help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
                          "1 = frame by frame, aipt_frame) and run the denoiser passes of consecutive frames on two streams, "
-                         "level by level behind each other.  Default: 8")
-    ap.add_argument("--prefetch", action="store_true",
-                    help="also trace the next batch (frame) on a low-priority second stream during the denoiser passes of this "
-                         "one (+9 %% on configs[2], but the streams' kernels fight for CUs on the reflective scene: off by default)")
+                         "level by level behind each other.  Default: 32 (traced 8 at a time)")
     ap.add_argument("--trace-flags", type=int, default=None, help="AIPT_TRACE_* bits (default AA | COMPACT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
@@ -93,7 +92,7 @@ def parse_args():
     args.mesh_kind = args.mesh_kind or kind or "atrium"
     args.impl = args.impl or impl
     if args.batch is None:
-        args.batch = 8
+        args.batch = 32
     return args
 
 
@@ -218,15 +217,8 @@ def main():
             if nb > 1:
                 ctx.frames(cams[k:k + nb], 1, depth, outs[:nb], trace_flags=trace_flags, bn_batch=bn_batch,
                            carry_first=carry and k > 0, carry=carry)
-                nn = min(B, k1 - (k + nb))
-                if args.prefetch and nn > 1:                  # next batch's trace on the side stream during these denoiser passes
-                    ctx.frames_prefetch(cams[k + nb:k + nb + nn], 1, depth, trace_flags)
             else:
                 ctx.frame(cams[k], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry and k > 0)
-                # pipelining: frame k+1 is traced on the side stream while frame k is denoised -- never across the
-                # warmup/timed boundary or past the last frame, so the timed region holds exactly K traces and K denoises
-                if args.prefetch and k + 1 < k1:
-                    ctx.frame_prefetch(cams[k + 1], 1, depth, trace_flags)
             k += nb
 
     def barrier():
@@ -264,15 +256,16 @@ def main():
 
     # ---- timed region: exactly K frames
     # HIP-event pairs around the launches of the dominant conv kernel and of the bounce kernel, on the launch stream, on the
-    # first frame of every third batch of the timed region (frame by frame: every 4th frame).  The library runs a timed forward pass ALONE (the
+    # first frame of every batch of 16+ frames of the timed region (smaller batches: every third; frame by frame: every 4th frame).  The library runs a timed forward pass ALONE (the
     # other denoiser stream drains before it and resumes after it), so a pair brackets the kernel and not its overlap with
-    # the next frame's launches; that costs the first two frames of every third batch their overlap (~2 % of `value`).
-    PROF_EVERY = 3 * B if B >= 4 else 4
+    # the next frame's launches; that costs the first two frames of those batches their overlap (~2 % of `value`).
+    PROF_EVERY = B if B >= 16 else 3 * B if B >= 4 else 4
     if prof_layers:
         nrec = (args.steps + PROF_EVERY - 1) // PROF_EVERY
         ctx.profile_stride(PROF_EVERY)
         ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
-        ctx.trace_profile_begin(nrec if B == 1 else (args.steps + B - 1) // B + 1, PROF_EVERY if B == 1 else 1)
+        # batched: every trace call is recorded (a call holds up to 8 frames; an aipt_frames batch is traced in such calls)
+        ctx.trace_profile_begin(nrec if B == 1 else (args.steps + 7) // 8 + (args.steps + B - 1) // B + 1, PROF_EVERY if B == 1 else 1)
     barrier()
     t0 = time.perf_counter()
     run_frames(args.warmup, per_rank)
@@ -400,7 +393,6 @@ def main():
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
                        "pipelining": ((f"traces of {B} consecutive frames share their launches and their denoiser passes run on two "
                                        f"streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else "frame by frame")
-                                      + ("; the next batch is traced on a second stream during the denoiser passes" if args.prefetch else "")
                                       + "; frames bit-identical to un-pipelined rendering")},
             "roofline": roof,
             "roofline_other": other,

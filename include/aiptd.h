@@ -241,10 +241,12 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
  * frames.  Only iter == 1 frames can be prefetched (planes 3-9 of later iterations live in the buffer iteration 1 wrote):
  * other values return AIPT_E_INVALID.  aipt_sync waits for both streams. */
 int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
-/* Frame batches: aipt_frames_configure(batch <= 8) after aipt_frame_configure; aipt_frames traces nframes consecutive frames
- * with one set of launches (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the others with
- * dn_flags_rest (e.g. carry the hidden state inside the batch) -- into d_out3[0..nframes).  Same results as nframes calls of
- * aipt_frame.  aipt_frame_last_times then reports per-frame averages over the batch. */
+/* Frame batches: aipt_frames_configure(batch <= 32) after aipt_frame_configure; aipt_frames traces nframes consecutive frames
+ * with one set of launches per 8 frames (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the
+ * others with dn_flags_rest (e.g. carry the hidden state inside the batch) -- into d_out3[0..nframes).  The denoiser passes of
+ * consecutive frames run on two streams, frame n+1 entering an encoder level when frame n has left it (its hidden state of
+ * that level is written); everything is joined on the context's stream before the call returns.  Same results, bit for bit,
+ * as nframes calls of aipt_frame.  aipt_frame_last_times then reports per-frame averages over the batch. */
 int aipt_frames_configure(aipt_ctx* ctx, int batch);
 int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
                 uint32_t dn_flags_first, uint32_t dn_flags_rest, float* const* d_out3);

@@ -91,8 +91,9 @@ def test_cli_ranks_sharing_one_gpu_render_byte_identical_frames(tmp_path):
         assert np.array_equal(g1.view(np.uint32), g4.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d4.view(np.uint32))
     _run_cli(scene, tmp_path / "c1", "--frames", "8", "--hidden", "carry", "--reset-every", "4")
     _run_cli(scene, tmp_path / "c2", "--frames", "8", "--hidden", "carry", "--gpus", "1", "--ranks", "2")
-    for (g1, d1), (g2, d2) in zip(_frames(tmp_path / "c1", 8), _frames(tmp_path / "c2", 8)):
-        assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    for k, ((g1, d1), (g2, d2)) in enumerate(zip(_frames(tmp_path / "c1", 8), _frames(tmp_path / "c2", 8))):
+        assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)), ("G-buffer", k, int((g1 != g2).sum()))
+        assert np.array_equal(d1.view(np.uint32), d2.view(np.uint32)), ("denoised", k, float(np.abs(d1 - d2).max()))
     # and the carried run differs from the reset run after the first frame of a chunk (the state really is carried)
     assert not np.array_equal(_frames(tmp_path / "c1", 2)[1][1], _frames(tmp_path / "r1", 2)[1][1])
 

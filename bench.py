@@ -325,6 +325,10 @@ def main():
                      "kernel": conv_dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
                      "ms_per_frame": round(avg_ms * len(prof_layers), 4),
                      "launches_timed": launches,
+                     "timing_note": ("the kernel ALONE: a timed forward pass runs with the other denoiser stream drained; in the "
+                                     "other frames two forward passes overlap, and rocprofv3's per-launch durations of the same "
+                                     "command include that overlap (profiles/: kernel_stats vs kernel_stats_one_denoiser_stream)"
+                                     if B > 1 else "frame by frame: one stream"),
                      "algorithmic_bytes_per_launch": bytes_per_frame / len(prof_layers),
                      "flops_per_launch": flops_per_frame / len(prof_layers),
                      "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma": mfma, "hbm": hbm,

@@ -1,0 +1,13 @@
+#!/bin/bash
+# gpurun_out/ev (tools/collect_evidence.sh) -> profiles/<round>_*: bench lines, kernel stats, PMC summaries
+set -eu
+R=${1:?round tag, e.g. r02}
+E=gpurun_out/ev
+for f in $E/bench_*.json; do n=$(basename $f); cp $f profiles/${R}_$n; done
+cp $E/layers.txt profiles/${R}_layers.txt
+cp $(find $E/kstats -name "*kernel_stats.csv" | head -1) profiles/${R}_kernel_stats.csv
+cp $(find $E/kstats_one_stream -name "*kernel_stats.csv" | head -1) profiles/${R}_kernel_stats_one_denoiser_stream.csv
+cp $E/pmc_dominant.json profiles/pmc_dominant.json
+cp $E/pmc_trace.json profiles/${R}_pmc_trace.json
+cp $E/pmc_conv.json profiles/${R}_pmc_conv.json
+ls profiles | grep "^${R}_"

@@ -39,11 +39,18 @@ def per_launch(path, counter):
 
 
 def main():
-    fcsv, wcsv = sys.argv[1:3]
-    kernels = sys.argv[3:]
+    args = sys.argv[1:]
+    outpath = None
+    if "--out" in args:                                # default: profiles/pmc_dominant.json of this checkout
+        i = args.index("--out")
+        outpath = args[i + 1]
+        del args[i:i + 2]
+    fcsv, wcsv = args[0:2]
+    kernels = args[2:]
     f, w = per_launch(fcsv, "FETCH_SIZE"), per_launch(wcsv, "WRITE_SIZE")
     out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the default bench.py command "
-                     "(--steps 8 --warmup 4 --no-cpu-baseline --no-roofline-events); KiB -> bytes; FETCH_SIZE doubled per "
+                     "with one denoiser stream (AIPT_DN_PIPELINE=0 ... --steps 16 --warmup 8 --no-cpu-baseline --no-roofline-events: "
+                     "a chip-wide counter belongs to one kernel only while one kernel runs); KiB -> bytes; FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; the BVH walk's 16-byte gathers are not "
                      "the calibrated pattern, so its figure is an upper bound); WRITE_SIZE uncalibrated; averaged over all "
                      "launches of the kernel in the run (tools/pmc_summarize.py)",
@@ -56,9 +63,9 @@ def main():
         out["kernels"][k] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch,
                              "write_bytes_per_launch": write, "launches_averaged": [len(f[k]), len(w[k])]}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with open(os.path.join(root, "profiles", "pmc_dominant.json"), "w") as fh:
+    with open(outpath or os.path.join(root, "profiles", "pmc_dominant.json"), "w") as fh:
         json.dump(out, fh, indent=1)
-    print(json.dumps(out["kernels"]))
+    print(json.dumps(out["kernels"]), file=sys.stderr)
 
 
 if __name__ == "__main__":

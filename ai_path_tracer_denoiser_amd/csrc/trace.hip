@@ -653,7 +653,6 @@ __device__ __forceinline__ int pool_blocks(int n) {                 // 256-path 
     const int k = n / (256 * 512);                                  // keep >= 512 workgroups
     return k < 1 ? 1 : k > POOL_BLOCKS ? POOL_BLOCKS : k;
 }
-template <bool FIRST>
 __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int2* s_res,
                                           WalkStack& st, int lane) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
@@ -680,17 +679,8 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
                 if (k < pool_n) {
                     lid = s_pool[k];
                     const int i = s_res[lid].x;                     // the path index, parked there by the listing phase
-                    v3 o, d;
-                    if (FIRST) {
-                        int pix = i, fr = 0;
-                        if (p.nframes > 1) { pix = i / p.nframes; fr = i - pix * p.nframes; }
-                        camera_ray(p, pix, fr, o, d);
-                    } else {
-                        const float4 a = S0[i], b = S1[i];
-                        o = V(a.x, a.y, a.z);
-                        d = V(a.w, b.x, b.y);
-                    }
-                    r.start(o, d, FLT_MAX);
+                    const float4 a = S0[i], b = S1[i];
+                    r.start(V(a.x, a.y, a.z), V(a.w, b.x, b.y), FLT_MAX);
                     cur = 0;
                     st.sp = 0;
                 }
@@ -725,7 +715,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
 #endif
 template <bool FIRST, bool MESH, bool POOL = false>
 __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
-    static_assert(MESH || !POOL, "the pool holds mesh walks");
+    static_assert((MESH && !FIRST) || !POOL, "the pool holds the mesh walks of the later bounces (bounce 0: coherent camera rays)");
     __shared__ int s_wave[4];
     __shared__ int s_pool_n, s_head;
     // dynamic LDS: [MESH: STACK_LDS x 256 stack words][POOL: pool, results][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)],
@@ -745,7 +735,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     const int n_in = FIRST ? p.PT : p.n_live[p.bounce];
     const int K = POOL ? pool_blocks(n_in) : 1;
     const int vb0 = blockIdx.x * K;
-    if ((!FIRST || POOL) && vb0 * 256 >= n_in) {          // whole workgroup beyond the list
+    if (!FIRST && vb0 * 256 >= n_in) {                   // whole workgroup beyond the list
         if ((int)(blockIdx.x * 256) >= n_in && (int)blockIdx.x < p.nblk) {     // (a lower block index belongs to a pooling workgroup)
             if (tid == 0) p.cnt[blockIdx.x] = 0;
             if (p.nframes > 1 && tid < p.nframes) p.cntf[blockIdx.x * BMAX + tid] = 0;
@@ -778,20 +768,11 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         for (int j = 0; j < K; j++) {
             const int t = (vb0 + j) * 256 + tid;
             const bool alive = t < n_in;
-            const int i = FIRST ? t : (alive ? p.live_in[t] : 0);
+            const int i = alive ? p.live_in[t] : 0;
             bool walker = false;
             if (alive && walk_mesh && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
-                v3 o, d;
-                if (FIRST) {
-                    int pix = i, fr = 0;
-                    if (p.nframes > 1) { pix = i / p.nframes; fr = i - pix * p.nframes; }
-                    camera_ray(p, pix, fr, o, d);
-                } else {
-                    const float4 a = S0[i], b = S1[i];
-                    o = V(a.x, a.y, a.z);
-                    d = V(a.w, b.x, b.y);
-                }
-                walker = rayAABB(o, d, p.box);                      // RAY_CULLING true (:23, :258)
+                const float4 a = S0[i], b = S1[i];
+                walker = rayAABB(V(a.x, a.y, a.z), V(a.w, b.x, b.y), p.box);      // RAY_CULLING true (:23, :258)
             }
             const unsigned long long m = __ballot(walker);
             int base = 0;
@@ -802,7 +783,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
         __syncthreads();
         WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0};
-        pool_walk<FIRST>(p, s_pool, s_pool_n, &s_head, s_res, st, lane);
+        pool_walk(p, s_pool, s_pool_n, &s_head, s_res, st, lane);
         __syncthreads();
         PHASE(2);
     }
@@ -1544,9 +1525,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     const size_t stack_bytes = (mesh ? (size_t)STACK_LDS * 256 * sizeof(int) : 0) + lds_scene;     // dynamic LDS of the bounce kernels
     // batched traces of a mesh scene pool their walks (see pool_walk); AIPT_TRACE_POOL=0/1 forces the choice (experiments)
     static const int pool_env = getenv("AIPT_TRACE_POOL") ? atoi(getenv("AIPT_TRACE_POOL")) : -1;
-    const bool pool = mesh && (pool_env < 0 ? nframes > 1 : pool_env != 0);
+    // (from 4 frames on: at 2 frames both walks take 0.82 ms per frame, single frames lose 10 %; never on bounce 0, whose camera
+    // rays are coherent -- 0.48 SIMD efficiency in the fused walk -- and would be generated twice: 415 vs 476 us at 8 frames)
+    const bool pool = mesh && (pool_env < 0 ? nframes >= 4 : pool_env != 0);
     const size_t pool_bytes = stack_bytes + (size_t)POOL_BLOCKS * 256 * 3 * sizeof(int);
-    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
+    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s,false>", mesh ? "true" : "false");
     snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
     int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)
     for (int b = 0; b < depth; b++) {
@@ -1557,8 +1540,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         if (nframes > 1) { p.rank_in = cur < 0 ? nullptr : s->d_rank[cur]; p.rank_out = s->d_rank[nxt]; }
         hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
-        if (b == 0 && pool) hipLaunchKernelGGL((trace_bounce<true, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
-        else if (pool) hipLaunchKernelGGL((trace_bounce<false, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
+        if (b > 0 && pool) hipLaunchKernelGGL((trace_bounce<false, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
         else if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);

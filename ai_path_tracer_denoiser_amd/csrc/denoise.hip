@@ -467,6 +467,12 @@ struct ConvArgsH {
     int sc;
     int d2s;                       // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to pixel (2y+a, 2x+b), channel j
     int tiles_x, tiles_y, groups;
+    // fused 2x2 max pool of the consumers' view of this output (encoder blocks): the consumers see lrelu(a*x + b) with
+    // a = gamma * rstd, which is monotone in x with the sign of gamma -- known at launch -- so the pooled tensor is the RAW
+    // output's 2x2 max (gamma >= 0) or min (gamma < 0), normalised by its consumers like any raw tensor: the same value,
+    // bit for bit, as pooling the normalised tensor, without a pass over it (pool2_norm: 5 launches, 57 us per frame)
+    float* pool_out;               // [ceil(cout/4)][H/2][W/2][4] or nullptr
+    const float* pool_gamma;       // [cout]
 };
 
 template <int RW, int NWV>
@@ -733,6 +739,41 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 const int x = tx0 + 8 * (k >> 2) + 4 * lg + (k & 3);
                 const float m = (y < H && x < W) ? t[k] : 0.0f;
                 s1 += m; s2 = fmaf(m, m, s2);
+            }
+        }
+        if (RW == 1 && g.pool_out) {
+            // 2x2 pool of the raw output: horizontal pairs are register pairs (pixels 2m, 2m+1 of this lane's 16), vertical
+            // pairs are the rows of waves 2v and 2v+1 -- through LDS (behind the BN reduction slots; the loop's last barrier
+            // has passed); the even wave stores 16 pooled pixels x 32 channels as C4 quads
+            const bool pos = j >= g.cout || !(g.pool_gamma[j] < 0.0f);
+            float hv[8];
+#pragma unroll
+            for (int m = 0; m < 8; m++) hv[m] = pos ? fmaxf(t[2 * m], t[2 * m + 1]) : fminf(t[2 * m], t[2 * m + 1]);
+            float* pbuf = reinterpret_cast<float*>(smem) + 1024 + wave * 8 * 64;
+            if (wave & 1) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) pbuf[m * 64 + lane] = hv[m];
+            }
+            __syncthreads();
+            if (!(wave & 1)) {
+                const float* qbuf = pbuf + 8 * 64;                  // the odd wave below
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const float o = qbuf[m * 64 + lane];
+                    hv[m] = pos ? fmaxf(hv[m], o) : fminf(hv[m], o);
+                }
+                // pooled pixel of hv[m]: x' = 4*(m>>1) + 2*lg + (m&1); lanes 4c..4c+3 hold channels 4c..4c+3
+                const int hh = H >> 1, hw = W >> 1;
+                float* prow = g.pool_out + (((size_t)(j >> 2) * hh + (y >> 1)) * hw + (tx0 >> 1)) * 4;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    float v[4] = {hv[half * 4], hv[half * 4 + 1], hv[half * 4 + 2], hv[half * 4 + 3]};
+                    quad_transpose_dpp(v, lane);
+                    const int mi = half * 4 + (lane & 3);
+                    const int xp = 4 * (mi >> 1) + 2 * lg + (mi & 1);
+                    if (quad_ok && y < H && tx0 + 2 * xp < W)
+                        *reinterpret_cast<f32x4*>(prow + xp * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                }
             }
         }
         if (g.d2s) {
@@ -1263,8 +1304,16 @@ static int conv_nblk(const TileChoice& t, int H, int W) {
 }
 
 // conv + (stats ->) finalize.  `dst` receives the raw output and its (a,b).
+// true when the conv of an h x w level runs on the split-fp16 kernel in a one-row-per-wave instantiation: those fuse the 2x2
+// pool of an encoder block's output into their epilogue (ConvArgsH::pool_out)
+static bool conv_fuses_pool(const DenoiseState* s, int H, int W) {
+    static const bool on = !getenv("AIPT_DN_FUSED_POOL") || atoi(getenv("AIPT_DN_FUSED_POOL")) != 0;
+    static const bool one_row = !getenv("AIPT_F16_WAVES") || atoi(getenv("AIPT_F16_WAVES")) == 8;
+    return on && impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels() && ((long)H * W < f16_min_pixels() || one_row);
+}
+
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
-                    int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b) {
+                    int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr) {
     const LayerW& L = s->L[li];
     ConvArgs g;
     g.a = ConvSrc{A.p, A.bn, A.C, upA, A.slope, A.planar};
@@ -1303,6 +1352,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
+        gh.pool_out = nullptr; gh.pool_gamma = nullptr;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
@@ -1346,6 +1396,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
+        gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
         f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
@@ -1700,15 +1751,22 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
         AIPT_HIP(ctx, wait_hidden(i));
         if ((rc = run_conv(ctx, s, li++, X.T1[i], 0, &prevX.Hid[i], 0, h, w, 1, X.T2[i], batch, carry))) return rc;
         Tensor t2 = X.T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
-        if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, X.Hid[i], batch, false))) return rc;
+        const bool fused_pool = conv_fuses_pool(s, h, w);
+        if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, X.Hid[i], batch, false, fused_pool ? &X.P[i] : nullptr))) return rc;
         X.Hid[i].slope = SLOPE;
         AIPT_HIP(ctx, hidden_written(i));
-        const size_t n = (size_t)(h / 2) * (w / 2);                         // one thread per pooled pixel of a channel quad
-        const int quads = pad4(ENC_CH[i]) / 4;
-        int grid = (int)((n + 255) / 256);
-        if (grid * quads > 4096) grid = (4096 + quads - 1) / quads;
-        hipLaunchKernelGGL(pool2_norm, dim3(grid, quads), dim3(256), 0, st, X.Hid[i].p, X.Hid[i].bn, SLOPE,
-                           ENC_CH[i], h, w, X.P[i].p);
+        if (fused_pool) {
+            // the conv left the pooled RAW output (max or min by the sign of gamma): its consumers normalise it like Hid[i]
+            X.P[i].bn = X.Hid[i].bn; X.P[i].slope = SLOPE;
+        } else {
+            const size_t n = (size_t)(h / 2) * (w / 2);                     // one thread per pooled pixel of a channel quad
+            const int quads = pad4(ENC_CH[i]) / 4;
+            int grid = (int)((n + 255) / 256);
+            if (grid * quads > 4096) grid = (4096 + quads - 1) / quads;
+            hipLaunchKernelGGL(pool2_norm, dim3(grid, quads), dim3(256), 0, st, X.Hid[i].p, X.Hid[i].bn, SLOPE,
+                               ENC_CH[i], h, w, X.P[i].p);
+            X.P[i].bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0}; X.P[i].slope = 1.0f;
+        }
         x = &X.P[i];
     }
     {   // bottleneck: conv-BN-LReLU three times

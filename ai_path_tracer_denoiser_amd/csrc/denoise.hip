@@ -447,6 +447,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// -DAIPT_ONE_ACC (experiment): both halves of the split accumulate into ONE fp32 accumulator.  Activations are staged times
+// 2^4 and weights stored times 2^7, their low halves unscaled relative to those (normal fp16 numbers for |x| >= 2^-7,
+// |w| >= 2^-10; smaller ones lose bits below 2^-25 of the unscaled value), the result is scaled back by 2^-11.
+#ifdef AIPT_ONE_ACC
+constexpr float XS = 16.0f, WS = 128.0f, LO_SCALE = 1.0f;
+#else
+constexpr float XS = 1.0f, WS = 1.0f, LO_SCALE = 2048.0f;
+#endif
 constexpr int KH = 16;             // input channels per chunk of the fp16 kernel
 constexpr int PXB = 48;            // bytes per pixel / per weight row in LDS (16 halfs + 8 halfs padding)
 constexpr int WSLAB = 2 * 9 * 32 * KH * 2;   // bytes of one (group, chunk) weight slab: hi and lo
@@ -588,11 +596,19 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const unsigned char* wslab = g.wsplit + (size_t)tile.gz * g.wchunks * WSLAB + tid * 16;
 
     const float bj = g.bias[n0 + li];
+#ifdef AIPT_ONE_ACC
+    f32x16 acc0[RW];
+#pragma unroll
+    for (int r = 0; r < RW; r++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc0[r][k] = 0.f;
+#else
     f32x16 acc0[RW], acc1[RW];
 #pragma unroll
     for (int r = 0; r < RW; r++)
 #pragma unroll
         for (int k = 0; k < 16; k++) { acc0[r][k] = bj; acc1[r][k] = 0.f; }
+#endif
 
     f32x4 pa[NU];
     u32x4 pw[NWP];
@@ -640,7 +656,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
             const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
             const f32x4 hf = {(float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]};
-            const f32x4 d = (v - hf) * 2048.0f;
+            const f32x4 d = (v - hf) * LO_SCALE;
             const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]));
             const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(d[2], d[3]));
             if (u_in[j]) {
@@ -667,8 +683,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const ConvSrc& s = fa ? g.a : g.b;
         float2 t = make_float2(0.0f, 0.0f);
         if (c < s.C) t = bn_ab(s.bn, c);
-        tab_a[kc] = t.x;
-        tab_b[kc] = t.y;
+        tab_a[kc] = t.x * XS;                                  // (LeakyReLU is positively homogeneous: the scale commutes)
+        tab_b[kc] = t.y * XS;
     }
     CPH(11);
     // zeroed halo image: only tiles whose halo leaves the image need it (out-of-image units never write); an interior tile
@@ -704,9 +720,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bhi + Cfg::B_BYTES + boff);
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
+#ifdef AIPT_ONE_ACC
+                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
+                    if (!W16) acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc0[r], 0, 0, 0);
+                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc0[r], 0, 0, 0);
+#else
                     acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
                     if (!W16) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
                     acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc1[r], 0, 0, 0);
+#endif
                 }
             }
         }
@@ -725,7 +747,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         const int y = ty0 + wave * RW + r;
+#ifdef AIPT_ONE_ACC
+        f32x16 t = acc0[r] * (1.0f / (XS * WS)) + bj;
+#else
         f32x16 t = acc0[r] + acc1[r] * (1.0f / 2048.0f);
+#endif
         if (g.out_lrelu) {
 #pragma unroll
             for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
@@ -1548,11 +1574,11 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                 for (int v = 0; v < vco; v++)
                     for (int kc = 0; kc < nch * KH; kc++)
                         for (int t = 0; t < 9; t++) {
-                            const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t];
+                            const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t] * WS;
                             const _Float16 h = (_Float16)x;
                             const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v) * KH + (kc % KH);
                             ws[o] = h;
-                            ws[o + 9 * 32 * KH] = (_Float16)((x - (float)h) * 2048.0f);
+                            ws[o + 9 * 32 * KH] = (_Float16)((x - (float)h) * LO_SCALE);
                         }
                 unsigned char*& dst_w = rounded ? L.d_wsplit_d2s16 : L.d_wsplit_d2s;
                 AIPT_HIP(ctx, hipMalloc((void**)&dst_w, ws.size() * 2));
@@ -1574,12 +1600,12 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                 for (int c = 0; c < L.cin; c++) {
                     const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
                     for (int t = 0; t < 9; t++) {
-                        const float v = w[((size_t)j * L.cin + c) * 9 + t];
+                        const float v = w[((size_t)j * L.cin + c) * 9 + t] * WS;
                         const _Float16 h = (_Float16)v;
                         const size_t slab = ((size_t)(j / 32) * L.nchunks16 + kc / KH) * (WSLAB / 2);
                         const size_t o = slab + ((size_t)t * 32 + (j % 32)) * KH + (kc % KH);
                         ws[o] = h;
-                        ws[o + 9 * 32 * KH] = (_Float16)((v - (float)h) * 2048.0f);
+                        ws[o + 9 * 32 * KH] = (_Float16)((v - (float)h) * LO_SCALE);
                     }
                 }
             std::vector<float> b32(L.coutp32, 0.0f);

@@ -76,7 +76,6 @@ void aipt_destroy(aipt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     for (hipStream_t ps : ctx->pipe) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t ev : ctx->ev_join) if (ev) hipEventDestroy(ev);
@@ -168,12 +167,6 @@ static inline int round_up32(int v) { return (v + 31) & ~31; }
 namespace aipt {
 // the prefetch stream runs at the lowest priority: its trace workgroups fill what the denoiser leaves idle instead of
 // delaying the convolutions of the frame being denoised (which are on the critical path of the sequence)
-hipError_t create_side_stream(aipt_ctx* ctx) {
-    int least = 0, greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (e != hipSuccess) return e;
-    return hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, least);
-}
 }  // namespace aipt
 
 int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
@@ -186,7 +179,6 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     if (rc) return rc;
     rc = aipt_denoise_configure(ctx, hp, wp);
     if (rc) return rc;
-    if (ctx->side) AIPT_HIP(ctx, hipStreamSynchronize(ctx->side));
     for (float*& g : ctx->d_gbufs) if (g) { hipFree(g); g = nullptr; }
     for (float*& g : ctx->d_gbatches) if (g) { hipFree(g); g = nullptr; }
     ctx->d_gbatch = nullptr; ctx->bpf.valid = false; ctx->bdenoised_valid[0] = ctx->bdenoised_valid[1] = false;
@@ -202,7 +194,7 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     }
     ctx->d_gbuf = ctx->d_gbufs[0];
     ctx->fw = width; ctx->fh = height; ctx->fwp = wp; ctx->fhp = hp;
-    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the zero fills are done before any stream (side included) traces
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->stream));          // the zero fills are done before any stream traces
     return AIPT_OK;
 }
 
@@ -321,9 +313,7 @@ int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, i
     // the frames' denoiser passes rotate over AIPT_DN_PIPE streams, each frame following the one before it level by level
     // (denoise_run): fork after the trace, join before anything that follows on the context's stream
     static const bool pipe_env = !getenv("AIPT_DN_PIPELINE") || atoi(getenv("AIPT_DN_PIPELINE")) != 0;
-    // (not together with aipt_frames_prefetch: a third, low-priority stream of trace launches beside the two denoiser
-    // streams collapsed to 52 frames/s on configs[2])
-    const bool pipelined = pipe_env && nframes > 1 && !ctx->side;
+    const bool pipelined = pipe_env && nframes > 1;
     if (pipelined) {
         if (!ctx->ev_fork) {
             for (int k = 0; k < AIPT_DN_PIPE - 1; k++) {
@@ -362,13 +352,14 @@ int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, in
     if (!cams || nframes < 1 || nframes > ctx->fbatch) return fail(ctx, AIPT_E_INVALID, "aipt_frames_prefetch: %d frames, configured for %d", nframes, ctx->fbatch);
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frames_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->side) AIPT_HIP(ctx, aipt::create_side_stream(ctx));
     const int back = ctx->bfront ^ 1;
-    // the denoiser passes that last read the back G-buffers must be done before the trace overwrites them
-    if (ctx->bdenoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_bdenoised[back], 0));
-    const int rc = trace_frames(ctx, ctx->side, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back]);
+    // On the context's stream, behind the denoiser passes already queued: bounce kernels that run BESIDE conv3x3_f16x3
+    // workgroups return wrong values for runs of up to 16 consecutive lanes in a few per cent of the frames (DESIGN.md,
+    // "Known issue"; tools/concurrency_probe.py), so the library never overlaps the two.  The call still moves the trace
+    // ahead of the host's next aipt_frames and keeps the double buffer.
+    const int rc = trace_frames(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back]);
     if (rc) return rc;
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->stream));
     ctx->bpf.valid = true; ctx->bpf.cams.assign(cams, cams + nframes); ctx->bpf.iter = iter; ctx->bpf.depth = depth;
     ctx->bpf.flags = trace_flags; ctx->bpf.buf = back;
     return AIPT_OK;
@@ -394,13 +385,11 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     // later iteration traced into the OTHER buffer would be denoised with stale planes, so only iteration 1 can be prefetched
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    if (!ctx->side) AIPT_HIP(ctx, aipt::create_side_stream(ctx));
     const int back = ctx->front ^ 1;
-    // the denoise that last read the back G-buffer must be done before the trace overwrites it
-    if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_denoised[back], 0));
-    const int rc = aipt::trace_on_stream(ctx, ctx->side, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
+    // on the context's stream, behind the denoise already queued (see aipt_frames_prefetch: no bounce kernel beside a conv)
+    const int rc = aipt::trace_on_stream(ctx, ctx->stream, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
     if (rc) return rc;
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->side));
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->stream));
     ctx->pf.valid = true; ctx->pf.cam = *cam; ctx->pf.iter = iter; ctx->pf.depth = depth; ctx->pf.flags = trace_flags;
     ctx->pf.buf = back;
     return AIPT_OK;

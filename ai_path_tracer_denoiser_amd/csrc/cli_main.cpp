@@ -28,6 +28,7 @@
 #include <string>
 #include <sys/stat.h>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -206,6 +207,10 @@ struct Shared {
     aipt_camera cam0;
     float zoom, phi0, theta;
     int W, H, depth;
+    // ranks that SHARE a GPU (--ranks R > --gpus N: the one-GPU check of sharded rendering) take their GPU's lock around
+    // every frame call: a bounce kernel running beside another rank's conv kernels returns wrong values for a few lanes in
+    // a few per cent of the frames (DESIGN.md "Known issue"), so their GPU work never overlaps
+    std::mutex* gpu_lock = nullptr;          // [gpus], or nullptr when every rank has its own GPU
 };
 
 // one rank's share of the frame sequence: frames [f0, f1), file names by global frame index
@@ -240,8 +245,13 @@ void render(const Shared& sh, Rank& rk) {
         }
         uint32_t f_first = o.dn_flags;
         if (k == rk.f0 || (o.reset_every > 0 && k % o.reset_every == 0)) f_first &= ~AIPT_DN_HIDDEN_CARRY;   // chunk start
-        if (B > 1) rc = aipt_frames(ctx, cams.data(), nb, 1, sh.depth, o.tr_flags, f_first, o.dn_flags, d_out.data());
-        else rc = aipt_frame(ctx, &cams[0], 1, sh.depth, o.tr_flags, f_first, d_out[0]);
+        {
+            std::unique_lock<std::mutex> hold;
+            if (sh.gpu_lock) hold = std::unique_lock<std::mutex>(sh.gpu_lock[rk.device - o.device]);
+            if (B > 1) rc = aipt_frames(ctx, cams.data(), nb, 1, sh.depth, o.tr_flags, f_first, o.dn_flags, d_out.data());
+            else rc = aipt_frame(ctx, &cams[0], 1, sh.depth, o.tr_flags, f_first, d_out[0]);
+            if (!rc && sh.gpu_lock) rc = aipt_sync(ctx);
+        }
         if (rc) return fail(B > 1 ? "aipt_frames" : "aipt_frame", rc);
         if (save) {
             float tms, dms;
@@ -425,6 +435,8 @@ int main(int argc, char** argv) {
     }
     // one host thread per rank (SURVEY 8b "Threading": one ctx per GPU, one host thread per ctx)
     const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::mutex> gpu_locks(o.gpus);
+    if (R > o.gpus) sh.gpu_lock = gpu_locks.data();
     if (R == 1) render(sh, ranks[0]);
     else {
         std::vector<std::thread> th;

@@ -40,8 +40,7 @@ struct aipt_ctx {
     float* d_gbuf = nullptr;      // [10][fhp][fwp]: the G-buffer of the last aipt_frame (= d_gbufs[front])
     float* d_gbufs[2] = {nullptr, nullptr};
     int front = 0;
-    // aipt_frame_prefetch: the next frame's trace runs on `side` into the back G-buffer while this frame is denoised
-    hipStream_t side = nullptr;
+    // aipt_frame_prefetch: the next frame's trace is queued (on `stream`) into the back G-buffer behind this frame's denoise
     // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
     // pipelined): AIPT_DN_PIPE frames in flight
     hipStream_t pipe[AIPT_DN_PIPE - 1] = {};
@@ -104,10 +103,9 @@ int build_bvh4(const aipt_face* faces, int nfaces, std::vector<Bvh4Node>& nodes,
 // (nframes > 1: a batch of frames traced by one set of launches, G-buffer f at d_gbuf + f * gbuf_frame floats)
 int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int nframes, int iter, int depth, uint32_t flags,
                     float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame);
-// wait for the main stream and, if one exists, the prefetch stream
+// wait for the main stream and the denoiser pipeline streams
 inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    if (e == hipSuccess && ctx->side) e = hipStreamSynchronize(ctx->side);
     for (hipStream_t ps : ctx->pipe)
         if (e == hipSuccess && ps) e = hipStreamSynchronize(ps);
     return e;

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Known issue probe: a context path-traces the same 8 frames over and over (comparing every G-buffer with its first run) while
+a second context on the same GPU denoises / traces / idles in another host thread.
+
+    python tools/concurrency_probe.py N denoise|trace|memset|none [DENOISER_H DENOISER_W]
+    PROBE_IMPL=0|1|2 (aggressor conv implementation: f32 MFMA, VALU, split-fp16), PROBE_FLAGS (victim AIPT_TRACE_* bits),
+    PROBE_DEPTH, PROBE_NOMESH=1, PROBE_LOCK=1 (host calls of the two threads never overlap)
+
+Measured (MI355X, ROCm 7.2, round 2): with the split-fp16 conv kernel running beside it, 3-8 % of the traced frames differ
+-- runs of 2..16 consecutive lanes ending at a 16-lane boundary get a different hit record / colour -- even for a depth-1,
+no-AA, primitives-only trace (one kernel launch).  0 of 6000 frames beside another trace, a memset loop, the f32-MFMA or
+the VALU conv kernels; the denoiser and torch kernels as victims: 0 of 3000.  Not an out-of-bounds write (1 MiB guard bands
+around every denoiser buffer and sentinel tensors stay intact), not host-side (PROBE_LOCK), not kernarg placement
+(HIP_FORCE_DEV_KERNARG), not a missing wait state or waitcnt (-mllvm -amdgpu-snop-padding / -amdgpu-waitcnt-forcezero
+builds), not dynamic LDS (static variant).  The library therefore never runs a bounce kernel beside a conv kernel."""
+import sys, os, threading, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ai_path_tracer_denoiser_amd import api, synth
+from tests.test_gpu_frame import _mesh_scene
+W, H, depth = 96, 64, int(os.environ.get('PROBE_DEPTH', '4'))
+sc, mats, faces, box = _mesh_scene((W, H), depth)
+FLAGS = int(os.environ.get('PROBE_FLAGS', '3'))
+if os.environ.get('PROBE_NOMESH'):
+    import numpy as _np
+    faces = faces[:0]
+cams = [sc.orbit(phi=sc.phi + 0.1 * k) for k in range(8)]
+N = int(sys.argv[1]); what = sys.argv[2]          # what the other thread does: denoise | trace | none | memset
+blob = synth.make_blob(565)
+A = api.Context(0); A.pathtrace_init(sc.geoms, mats, faces, box, W, H)
+B = api.Context(0); B.pathtrace_init(sc.geoms, mats, faces, box, W, H); B.load_weights(blob)
+DH, DW = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (H, W)
+B.denoise_configure(DH, DW)
+if os.environ.get('PROBE_IMPL'): B.denoise_set_impl(int(os.environ['PROBE_IMPL']))
+BNB = os.environ.get('PROBE_BN', '1') == '1'
+g = torch.zeros(10, H, W, device="cuda"); torch.cuda.synchronize()
+ref = []
+for c in cams:
+    A.pathtrace(c, 1, depth, g, FLAGS); A.sync(); ref.append(g.cpu().numpy().copy())
+LOCK = threading.Lock() if os.environ.get('PROBE_LOCK') else None
+import contextlib
+def locked():
+    return LOCK if LOCK else contextlib.nullcontext()
+stop = False
+def other():
+    gb = torch.from_numpy(synth.make_gbuffer(DH, DW, 3, 0)).cuda(); ob = torch.empty(3, DH, DW, device="cuda"); g2 = torch.zeros(10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    n = 0
+    while not stop:
+        if what == "denoise":
+            with locked(): B.denoise(gb, ob, bn_batch=BNB, carry=False)
+        elif what == "trace": B.pathtrace(cams[n % 8], 1, depth, g2)
+        elif what == "memset": ob.zero_()
+        else: time.sleep(0.001)
+        n += 1
+        if n % 8 == 0: B.sync()
+    B.sync()
+    print("other thread did", n, what)
+t = threading.Thread(target=other); t.start()
+bad = 0
+for it in range(N):
+    k = it % 8
+    with locked(): A.pathtrace(cams[k], 1, depth, g, FLAGS)
+    A.sync()
+    r = g.cpu().numpy()
+    n = int((r.view(np.uint32) != ref[k].view(np.uint32)).sum())
+    if n:
+        bad += 1
+        w = np.argwhere(r.view(np.uint32) != ref[k].view(np.uint32))
+        per_plane = [int((r[pl].view(np.uint32) != ref[k][pl].view(np.uint32)).sum()) for pl in range(10)]
+        pix = np.unique(w[:, 1] * W + (W - 1 - w[:, 2]))          # un-flipped pixel index (h-flipped destination)
+        blocks = sorted(set((pix // 256).tolist()))
+        vals = [(float(r[tuple(i)]), float(ref[k][tuple(i)])) for i in w[:3]]
+        print("iter", it, "frame", k, "words", n, "per plane", per_plane, "pixels", len(pix), "pixel idx range", int(pix.min()), int(pix.max()), "256-blocks", blocks[:12], "got/ref", vals, flush=True)
+stop = True; t.join()
+print("other =", what, "frames", N, "bad", bad)

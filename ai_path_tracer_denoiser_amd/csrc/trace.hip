@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     // every wave is full of live paths and the state planes are gathered/scattered through the pixel index.
     // primitives and materials into LDS: the candidate loop and the shader index them per lane
     const bool broad = p.ngeoms <= MAXG_LDS && !(p.flags & AIPT_TRACE_NO_BROAD_PHASE);
-    const bool mats_lds = p.nmats <= MAXM_LDS;
+    const bool mats_lds = p.nmats <= MAXM_LDS && !(p.flags & 0x10000000u);     // (bit 28: debug, materials from HBM)
     if (broad) {
         const int nw = p.ngeoms * (int)(sizeof(DevGeom) / 4);
         for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_geoms)[k] = reinterpret_cast<const int*>(p.geoms)[k];

@@ -4,7 +4,7 @@ a second context on the same GPU denoises / traces / idles in another host threa
 
     python tools/concurrency_probe.py N denoise|trace|memset|none [DENOISER_H DENOISER_W]
     PROBE_IMPL=0|1|2 (aggressor conv implementation: f32 MFMA, VALU, split-fp16), PROBE_FLAGS (victim AIPT_TRACE_* bits),
-    PROBE_DEPTH, PROBE_NOMESH=1, PROBE_LOCK=1 (host calls of the two threads never overlap)
+    PROBE_DEPTH, PROBE_NOMESH=1, PROBE_LOCK=1 (host calls of the two threads never overlap), PROBE_COMPARE_ON_GPU=1, PROBE_CU_SPLIT=1
 
 Measured (MI355X, ROCm 7.2, round 2): with the split-fp16 conv kernel running beside it, 3-8 % of the traced frames differ
 -- runs of 2..16 consecutive lanes ending at a 16-lane boundary get a different hit record / colour -- even for a depth-1,
@@ -12,7 +12,9 @@ no-AA, primitives-only trace (one kernel launch).  0 of 6000 frames beside anoth
 the VALU conv kernels; the denoiser and torch kernels as victims: 0 of 3000.  Not an out-of-bounds write (1 MiB guard bands
 around every denoiser buffer and sentinel tensors stay intact), not host-side (PROBE_LOCK), not kernarg placement
 (HIP_FORCE_DEV_KERNARG), not a missing wait state or waitcnt (-mllvm -amdgpu-snop-padding / -amdgpu-waitcnt-forcezero
-builds), not dynamic LDS (static variant).  The library therefore never runs a bounce kernel beside a conv kernel."""
+builds), not dynamic LDS (static variant), not LDS reads in the victim, not the device-to-host copy (PROBE_COMPARE_ON_GPU=1).
+It needs co-residency: PROBE_CU_SPLIT=1 (the two contexts' streams on disjoint halves of the CUs) gives 0 of 1500.
+The library therefore never runs a bounce kernel beside a conv kernel."""
 import sys, os, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,8 +30,19 @@ if os.environ.get('PROBE_NOMESH'):
 cams = [sc.orbit(phi=sc.phi + 0.1 * k) for k in range(8)]
 N = int(sys.argv[1]); what = sys.argv[2]          # what the other thread does: denoise | trace | none | memset
 blob = synth.make_blob(565)
-A = api.Context(0); A.pathtrace_init(sc.geoms, mats, faces, box, W, H)
-B = api.Context(0); B.pathtrace_init(sc.geoms, mats, faces, box, W, H); B.load_weights(blob)
+def masked_stream(lo, hi):
+    """a HIP stream restricted to CUs lo..hi-1 (hipExtStreamCreateWithCUMask), as a raw handle"""
+    import ctypes
+    import glob
+    hip = ctypes.CDLL(glob.glob(os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so*'))[0])   # the runtime torch has loaded
+    st = ctypes.c_void_p()
+    words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if lo <= w * 32 + b < hi) for w in range(8)])
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    assert rc == 0, rc
+    return st.value
+SPLIT = os.environ.get('PROBE_CU_SPLIT')                 # "1": victim on CUs 0-127, the other context on CUs 128-255
+A = api.Context(0, stream=masked_stream(0, 128) if SPLIT else None); A.pathtrace_init(sc.geoms, mats, faces, box, W, H)
+B = api.Context(0, stream=masked_stream(128, 256) if SPLIT else None); B.pathtrace_init(sc.geoms, mats, faces, box, W, H); B.load_weights(blob)
 DH, DW = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (H, W)
 B.denoise_configure(DH, DW)
 if os.environ.get('PROBE_IMPL'): B.denoise_set_impl(int(os.environ['PROBE_IMPL']))
@@ -38,6 +51,8 @@ g = torch.zeros(10, H, W, device="cuda"); torch.cuda.synchronize()
 ref = []
 for c in cams:
     A.pathtrace(c, 1, depth, g, FLAGS); A.sync(); ref.append(g.cpu().numpy().copy())
+refg = [torch.from_numpy(r).cuda() for r in ref]
+ONGPU = bool(os.environ.get('PROBE_COMPARE_ON_GPU'))
 LOCK = threading.Lock() if os.environ.get('PROBE_LOCK') else None
 import contextlib
 def locked():
@@ -63,6 +78,10 @@ for it in range(N):
     k = it % 8
     with locked(): A.pathtrace(cams[k], 1, depth, g, FLAGS)
     A.sync()
+    if ONGPU:                                           # compare on the device: no device-to-host copy of the G-buffer
+        n = int((g.view(torch.int32) != refg[k].view(torch.int32)).sum())
+        if n: bad += 1; print("iter", it, "frame", k, "words", n, "(compared on the GPU)", flush=True)
+        continue
     r = g.cpu().numpy()
     n = int((r.view(np.uint32) != ref[k].view(np.uint32)).sum())
     if n:
@@ -72,6 +91,9 @@ for it in range(N):
         pix = np.unique(w[:, 1] * W + (W - 1 - w[:, 2]))          # un-flipped pixel index (h-flipped destination)
         blocks = sorted(set((pix // 256).tolist()))
         vals = [(float(r[tuple(i)]), float(ref[k][tuple(i)])) for i in w[:3]]
+        prev = ref[(k - 1) % 8]                             # the frame traced into this buffer just before
+        stale = sum(1 for i in w if r[tuple(i)] == prev[tuple(i)])
+        print("   of the", n, "differing words", stale, "hold the PREVIOUS frame's value at that position", flush=True)
         print("iter", it, "frame", k, "words", n, "per plane", per_plane, "pixels", len(pix), "pixel idx range", int(pix.min()), int(pix.max()), "256-blocks", blocks[:12], "got/ref", vals, flush=True)
 stop = True; t.join()
 print("other =", what, "frames", N, "bad", bad)

@@ -6,6 +6,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 namespace aipt {
 
@@ -77,6 +78,7 @@ void aipt_destroy(aipt_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (hipStream_t ps : ctx->pipe) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
+    for (hipStream_t ps : {ctx->st_trace, ctx->st_dn}) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t ev : ctx->ev_join) if (ev) hipEventDestroy(ev);
     aipt::trace_destroy(ctx);
@@ -237,11 +239,19 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     ctx->d_gbuf = ctx->d_gbufs[ctx->front];
     ctx->last_batch = 1;
     if (ctx->frame_timing) AIPT_HIP(ctx, hipEventRecord(ctx->fev[1], ctx->stream));
-    // the final normalisation pass writes the cropped [3][h][w] image directly (no padded copy, no crop copies)
-    rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw);
+    // the final normalisation pass writes the cropped [3][h][w] image directly (no padded copy, no crop copies).
+    // A prefetched frame is denoised on the CU-masked denoiser stream, so that the NEXT prefetch's trace (on the disjoint
+    // CUs of st_trace) may run beside it; the pass follows the previous denoise (hidden state) and the prefetched trace.
+    hipStream_t dn = hit && ctx->st_dn ? ctx->st_dn : ctx->stream;
+    if (dn != ctx->stream) {
+        AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_prefetched, 0));
+        for (int b = 0; b < 2; b++) if (ctx->denoised_valid[b]) AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_denoised[b], 0));
+    }
+    rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw, false, dn != ctx->stream ? dn : nullptr);
     if (rc) return rc;
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], ctx->stream));
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], dn));
     ctx->denoised_valid[ctx->front] = true;
+    if (dn != ctx->stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_denoised[ctx->front], 0));   // join
     if (ctx->frame_timing) {
         AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
         ctx->frame_timed = true;
@@ -385,11 +395,25 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     // later iteration traced into the OTHER buffer would be denoised with stale planes, so only iteration 1 can be prefetched
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->st_trace) {
+        // two streams on disjoint CUs: the first AIPT_PREFETCH_TRACE_CUS (default: half) for the trace, the rest for the denoiser
+        hipDeviceProp_t prop;
+        AIPT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+        const int ncu = prop.multiProcessorCount;
+        static const int env_cus = getenv("AIPT_PREFETCH_TRACE_CUS") ? atoi(getenv("AIPT_PREFETCH_TRACE_CUS")) : 0;
+        const int nt = env_cus > 0 && env_cus < ncu ? env_cus : ncu / 2;
+        std::vector<uint32_t> mt((ncu + 31) / 32, 0u), md((ncu + 31) / 32, 0u);
+        for (int c = 0; c < ncu; c++) (c < nt ? mt : md)[c / 32] |= 1u << (c % 32);
+        AIPT_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->st_trace, (uint32_t)mt.size(), mt.data()));
+        AIPT_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->st_dn, (uint32_t)md.size(), md.data()));
+    }
     const int back = ctx->front ^ 1;
-    // on the context's stream, behind the denoise already queued (see aipt_frames_prefetch: no bounce kernel beside a conv)
-    const int rc = aipt::trace_on_stream(ctx, ctx->stream, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
+    // the trace follows everything queued on the context's stream so far except the denoise it is meant to overlap: the
+    // denoise that last read the back G-buffer (trace_on_stream orders it behind the previous trace by itself)
+    if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->st_trace, ctx->ev_denoised[back], 0));
+    const int rc = aipt::trace_on_stream(ctx, ctx->st_trace, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
     if (rc) return rc;
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->stream));
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->st_trace));
     ctx->pf.valid = true; ctx->pf.cam = *cam; ctx->pf.iter = iter; ctx->pf.depth = depth; ctx->pf.flags = trace_flags;
     ctx->pf.buf = back;
     return AIPT_OK;

@@ -1716,7 +1716,8 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
 // forward pass; the planar output is cropped to out_h x out_w (aipt_frame drops its padding here).  pipelined: the frame runs
 // on the stream of its activation set (set 0: the context's stream, set k: ctx->pipe[k-1]) and waits, level by level, for the
 // hidden states of the frame before it; the caller forks / joins the streams around a run of such frames.
-int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined) {
+int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined,
+                      hipStream_t on) {
     DenoiseState* s = state(ctx);
     if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise: call aipt_denoise_configure first");
@@ -1730,9 +1731,13 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     const int a = (s->aset + 1) % NSET, ap = s->aset;          // this frame's set; the previous frame's
     DenoiseState::ActSet& X = s->A[a];
     DenoiseState::ActSet& prevX = s->A[ap];
-    pipelined = pipelined && ctx->ev_fork;
+    pipelined = pipelined && ctx->ev_fork && !on;
     auto stream_of = [&](int set) { return set == 0 ? ctx->stream : ctx->pipe[set - 1]; };
-    hipStream_t st = pipelined ? stream_of(a) : ctx->stream;
+    hipStream_t st = on ? on : pipelined ? stream_of(a) : ctx->stream;     // on: the CU-masked denoiser stream of aipt_frame
+    // conv kernels never run beside a bounce kernel on the same CUs (DESIGN.md "Known issue"): unless this pass runs on the
+    // CU-masked denoiser stream, it starts after the last trace, whichever stream that ran on
+    if (ctx->last_trace_stream && ctx->last_trace_stream != st && st != ctx->st_dn)
+        AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
     s->cur = st;
     s->aset = a;
     // a forward pass whose launches are being timed (aipt_denoise_profile_*) runs alone: the other streams drain before it

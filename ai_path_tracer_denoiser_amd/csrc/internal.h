@@ -40,7 +40,10 @@ struct aipt_ctx {
     float* d_gbuf = nullptr;      // [10][fhp][fwp]: the G-buffer of the last aipt_frame (= d_gbufs[front])
     float* d_gbufs[2] = {nullptr, nullptr};
     int front = 0;
-    // aipt_frame_prefetch: the next frame's trace is queued (on `stream`) into the back G-buffer behind this frame's denoise
+    // aipt_frame_prefetch: the next frame's trace runs on `st_trace` into the back G-buffer while this frame is denoised on
+    // `st_dn` -- two streams restricted to DISJOINT sets of CUs (hipExtStreamCreateWithCUMask): a bounce kernel and a conv kernel
+    // must never share a CU (DESIGN.md "Known issue"), and a single frame's trace does not fill the chip anyway
+    hipStream_t st_trace = nullptr, st_dn = nullptr;
     // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
     // pipelined): AIPT_DN_PIPE frames in flight
     hipStream_t pipe[AIPT_DN_PIPE - 1] = {};
@@ -108,10 +111,13 @@ inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     for (hipStream_t ps : ctx->pipe)
         if (e == hipSuccess && ps) e = hipStreamSynchronize(ps);
+    if (e == hipSuccess && ctx->st_trace) e = hipStreamSynchronize(ctx->st_trace);
+    if (e == hipSuccess && ctx->st_dn) e = hipStreamSynchronize(ctx->st_dn);
     return e;
 }
 // aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)
-int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined = false);
+int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined = false,
+                hipStream_t on = nullptr);
 void trace_destroy(aipt_ctx* ctx);
 void denoise_destroy(aipt_ctx* ctx);
 

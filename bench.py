@@ -77,6 +77,9 @@ def parse_args():
                     help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
                          "1 = frame by frame, aipt_frame) and run the denoiser passes of consecutive frames on two streams, "
                          "level by level behind each other.  Default: 32 (traced 8 at a time)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="frame by frame (--batch 1) only: trace frame k+1 while frame k is denoised, the two on disjoint halves "
+                         "of the CUs (aipt_frame_prefetch; one frame of latency, same bits)")
     ap.add_argument("--trace-flags", type=int, default=None, help="AIPT_TRACE_* bits (default AA | COMPACT)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
@@ -219,6 +222,9 @@ def main():
                            carry_first=carry and k > 0, carry=carry)
             else:
                 ctx.frame(cams[k], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry and k > 0)
+                # never across the warmup/timed boundary or past the last frame: the timed region holds exactly K traces
+                if args.prefetch and k + 1 < k1:
+                    ctx.frame_prefetch(cams[k + 1], 1, depth, trace_flags)
             k += nb
 
     def barrier():
@@ -396,7 +402,8 @@ def main():
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
                        "pipelining": ((f"traces of {B} consecutive frames share their launches and their denoiser passes run on two "
-                                       f"streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else "frame by frame")
+                                       f"streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else
+                                      "frame by frame" + ("; the next frame's trace runs beside this frame's denoise on disjoint CUs" if args.prefetch else ""))
                                       + "; frames bit-identical to un-pipelined rendering")},
             "roofline": roof,
             "roofline_other": other,

@@ -234,14 +234,17 @@ int aipt_denoise_layer_info(aipt_ctx* ctx, int layer, char* kernel, size_t kerne
 int aipt_frame_configure(aipt_ctx* ctx, int width, int height);
 int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags, uint32_t dn_flags,
                float* d_out3);
-/* Early trace (no reference equivalent: runCuda traces and denoises strictly in turn, main.cpp:143-163).  Queues the path
- * trace of the NEXT frame into the context's back G-buffer right behind the denoise of the frame being processed, before the
- * host comes back with the next aipt_frame; that aipt_frame with an identical (cam, iter, depth, trace_flags) consumes it
- * instead of tracing.  A different request drops the prefetch.  Results are identical to frames without it.  (It ran on a
- * second stream, overlapping the denoise, until round 2: bounce kernels that run beside the split-fp16 conv kernel return
- * wrong values for a few lanes in a few per cent of the frames -- DESIGN.md "Known issue" -- so the library does not overlap
- * them.)  Only iter == 1 frames can be prefetched (planes 3-9 of later iterations live in the buffer iteration 1 wrote): other
- * values return AIPT_E_INVALID. */
+/* Throughput pipelining for frame-by-frame hosts (no reference equivalent: runCuda traces and denoises strictly in turn,
+ * main.cpp:143-163).  Starts the path trace of the NEXT frame into the context's back G-buffer on a stream restricted to
+ * half of the CUs; the following aipt_frame with an identical (cam, iter, depth, trace_flags) consumes it instead of tracing
+ * and runs its denoise on a stream restricted to the OTHER half, so that the next prefetch's trace runs beside it.  A
+ * different request drops the prefetch.  Results are identical to frames without it (one frame of latency, +33 % frames/s
+ * on the mesh configuration; on scenes whose trace is cheap the halved denoiser costs more than the overlap gains: do not
+ * prefetch there).  The two streams use DISJOINT CUs because a bounce kernel that shares a CU with the split-fp16 conv
+ * kernel returns wrong values for a few lanes in a few per cent of the frames (DESIGN.md "Known issue"); a single frame's
+ * trace does not fill the chip anyway.  AIPT_PREFETCH_TRACE_CUS overrides the split.  Only iter == 1 frames can be prefetched
+ * (planes 3-9 of later iterations live in the buffer iteration 1 wrote): other values return AIPT_E_INVALID.  aipt_sync waits
+ * for every stream of the context; work queued on the context's stream after aipt_frame sees its result. */
 int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
 /* Frame batches: aipt_frames_configure(batch <= 32) after aipt_frame_configure; aipt_frames traces nframes consecutive frames
  * with one set of launches per 8 frames (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the
@@ -253,8 +256,9 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch);
 int aipt_frames(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
                 uint32_t dn_flags_first, uint32_t dn_flags_rest, float* const* d_out3);
 int aipt_frames_gbuffer(aipt_ctx* ctx, int frame, float** d_gbuf, int* rows, int* stride);
-/* like aipt_frame_prefetch, for batches: queues the traces of the NEXT batch into the back set of G-buffers behind the
- * denoiser passes of the current one; the following aipt_frames with identical (cams, iter, depth, trace_flags) consumes it. */
+/* for batches: queues the traces of the NEXT batch into the back set of G-buffers BEHIND the denoiser passes of the current
+ * one, on the context's stream (a batch's traces fill the chip: nothing to gain from a CU split, and they must not share CUs
+ * with conv kernels); the following aipt_frames with identical (cams, iter, depth, trace_flags) consumes it. */
 int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags);
 /* the context-owned padded G-buffer float[10][Hp][Wp] of the last aipt_frame (device pointer) and its padded size */
 int aipt_gbuffer(aipt_ctx* ctx, float** d_gbuf, int* rows, int* stride);

@@ -41,7 +41,7 @@ def test_frame_sequence_matches_oracle():
 
 @pytest.mark.gpu
 def test_prefetch_pipeline_is_bit_identical():
-    """aipt_frame_prefetch (trace k+1 on the side stream during denoise k) must not change any output bit."""
+    """aipt_frame_prefetch (trace k+1 on its own CU-masked stream during denoise k) must not change any output bit."""
     import torch
     W, H, depth = 80, 48, 4                # pads to 96 x 64: the crop path is pipelined too
     sc = api.Scene(CORNELL, res=(W, H), depth=depth)
@@ -244,3 +244,36 @@ def test_pipelined_denoiser_passes_equal_the_sequential_ones(bn_batch, carry):
     got = run(8)
     for k in range(len(ref)):
         assert np.array_equal(got[k], ref[k]), (bn_batch, carry, k)
+
+
+def test_prefetch_on_disjoint_cus_is_bit_identical_at_a_size_that_overlaps():
+    """aipt_frame_prefetch traces frame k+1 on a CU-masked stream while frame k is denoised on the complementary CUs (a
+    bounce kernel must never share a CU with a conv kernel: DESIGN.md "Known issue").  A mesh scene at 640x352, where the two
+    really run side by side, 24 frames with the hidden state carried: every denoised frame must equal the frame-by-frame
+    run bit for bit (three repetitions)."""
+    import torch
+    W, H, depth = 640, 352, 4
+    sc, mats, faces, box = _mesh_scene((W, H), depth, ntri=32768)
+    cams = [sc.orbit(phi=sc.phi + 0.05 * k) for k in range(24)]
+    blob = synth.make_blob(13)
+
+    def run(prefetch):
+        ctx = api.Context(0)
+        ctx.pathtrace_init(sc.geoms, mats, faces, box)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        out = torch.empty(3, H, W, device="cuda")
+        res = []
+        for k, c in enumerate(cams):
+            ctx.frame(c, 1, depth, out, bn_batch=True, carry=k > 0)
+            if prefetch and k + 1 < len(cams):
+                ctx.frame_prefetch(cams[k + 1], 1, depth)
+            ctx.sync()
+            res.append(out.cpu().numpy().copy())       # batch-statistics BN: every output value depends on every G-buffer pixel
+        ctx.close()
+        return res
+    ref = run(False)
+    for rep in range(3):
+        got = run(True)
+        for k in range(len(ref)):
+            assert np.array_equal(got[k], ref[k]), (rep, k)

@@ -9,7 +9,7 @@
 //   aiptd scene.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE | --synthetic-weights SEED]
 //                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w] [--pan AMPLITUDE] [--device I]
 //                   [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]
-//                   [--gpus N] [--ranks R] [--shim] [--batch B] [--reset-every C]
+//                   [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]
 //
 // Multi-GPU (no reference equivalent: the reference is single-GPU; design SURVEY 8e): --gpus N runs one rank (one
 // host thread, one context) per GPU; rank r renders the contiguous frame chunk [r*F/R, (r+1)*F/R) -- contiguous so that a
@@ -19,7 +19,8 @@
 // replaces RCCL by an in-process copy shim, so a one-GPU box can check that sharded rendering is byte-identical
 // (tests/test_cli.py); --reset-every C makes a single rank drop the hidden state where R ranks would (every C frames).
 // --batch B (<= 32) traces B consecutive frames with one set of launches per 8 and pipelines their denoiser passes over two
-// streams (aipt_frames; identical results).
+// streams (aipt_frames; identical results).  --prefetch (frame by frame, every rank on its own GPU): the next frame's trace
+// runs beside this frame's denoise on disjoint halves of the CUs (aipt_frame_prefetch; identical results).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -188,6 +189,7 @@ struct Options {
     std::string scene_path, out_dir, weights_path, dump_weights;
     int frames = 1, res_w = 0, res_h = 0, depth = 0, device = 0, impl = AIPT_DN_IMPL_MFMA_F16X3;
     int gpus = 1, ranks = 0, batch = 1, reset_every = 0;
+    bool prefetch = false;
     bool npy = false, shim = false;
     uint64_t wseed = 565;
     uint32_t dn_flags = AIPT_DN_BN_BATCH | AIPT_DN_HIDDEN_CARRY, tr_flags = AIPT_TRACE_DEFAULT;
@@ -250,6 +252,12 @@ void render(const Shared& sh, Rank& rk) {
             if (sh.gpu_lock) hold = std::unique_lock<std::mutex>(sh.gpu_lock[rk.device - o.device]);
             if (B > 1) rc = aipt_frames(ctx, cams.data(), nb, 1, sh.depth, o.tr_flags, f_first, o.dn_flags, d_out.data());
             else rc = aipt_frame(ctx, &cams[0], 1, sh.depth, o.tr_flags, f_first, d_out[0]);
+            if (!rc && B == 1 && o.prefetch && !sh.gpu_lock && k + 1 < rk.f1) {     // the next frame's trace, beside this denoise
+                aipt_camera next = sh.cam0;
+                const float phi = sh.phi0 + o.pan * std::sin(2.0 * 3.14159265358979323846 * (k + 1) / 300.0);
+                aipt_camera_orbit(&next, sh.zoom, phi, sh.theta);
+                rc = aipt_frame_prefetch(ctx, &next, 1, sh.depth, o.tr_flags);
+            }
             if (!rc && sh.gpu_lock) rc = aipt_sync(ctx);
         }
         if (rc) return fail(B > 1 ? "aipt_frames" : "aipt_frame", rc);
@@ -260,6 +268,7 @@ void render(const Shared& sh, Rank& rk) {
         }
         for (int j = 0; j < nb && save; j++) {
             if (B > 1) aipt_frames_gbuffer(ctx, j, &d_gbuf, &rows, &stride);
+            else aipt_gbuffer(ctx, &d_gbuf, &rows, &stride);      // (with --prefetch the front G-buffer alternates)
             aipt_download(ctx, h_g.data(), d_gbuf, sizeof(float) * h_g.size());
             aipt_download(ctx, h_o.data(), d_out[j], sizeof(float) * h_o.size());
             char name[64];
@@ -304,7 +313,7 @@ int main(int argc, char** argv) {
         printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
                " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w]"
                " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]"
-               " [--gpus N] [--ranks R] [--shim] [--batch B] [--reset-every C]\n", argv[0]);
+               " [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]\n", argv[0]);
         return 1;
     }
     Shared sh;
@@ -337,6 +346,7 @@ int main(int argc, char** argv) {
         else if (a == "--ranks") { need(1); o.ranks = atoi(argv[++i]); }
         else if (a == "--shim") o.shim = true;
         else if (a == "--batch") { need(1); o.batch = atoi(argv[++i]); }
+        else if (a == "--prefetch") o.prefetch = true;
         else if (a == "--reset-every") { need(1); o.reset_every = atoi(argv[++i]); }
         else { fprintf(stderr, "aiptd: unknown option %s\n", a.c_str()); return 1; }
     }

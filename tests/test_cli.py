@@ -106,6 +106,9 @@ def test_cli_batched_frames_and_gpu_count_check(tmp_path):
     assert b3["batch"] == 3
     for (g1, d1), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / "b3", 7)):
         assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))
+    pf = _run_cli(scene, tmp_path / "pf", "--frames", "7", "--hidden", "carry", "--prefetch")     # trace k+1 beside denoise k
+    for (g1, d1), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / "pf", 7)):
+        assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))
     import torch
     n = torch.cuda.device_count()
     r = subprocess.run([CLI, scene, "--frames", "2", "--gpus", str(n + 1)], capture_output=True, text=True)

@@ -29,6 +29,7 @@ cp $O/pmc_dominant.json profiles/pmc_dominant.json
 $B > $O/bench_default.json 2> $O/bench_default.err
 $B --no-cpu-baseline --layers > /dev/null 2> $O/layers.txt
 $B --batch 1 --no-cpu-baseline > $O/bench_frame_by_frame.json 2>/dev/null
+$B --batch 1 --prefetch --no-cpu-baseline > $O/bench_frame_by_frame_prefetch.json 2>/dev/null
 AIPT_DN_PIPELINE=0 $B --no-cpu-baseline > $O/bench_one_denoiser_stream.json 2>/dev/null
 AIPT_TRACE_POOL=0 $B --no-cpu-baseline > $O/bench_fused_walk.json 2>/dev/null
 for c in 0 1 3 4; do $B --config $c --no-cpu-baseline > $O/bench_config$c.json 2>/dev/null; done

@@ -78,7 +78,7 @@ void aipt_destroy(aipt_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (hipStream_t ps : ctx->pipe) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
-    for (hipStream_t ps : {ctx->st_trace, ctx->st_dn}) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
+    for (hipStream_t ps : {ctx->st_trace, ctx->st_dn}) if (ps && ps != ctx->stream) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t ev : ctx->ev_join) if (ev) hipEventDestroy(ev);
     aipt::trace_destroy(ctx);
@@ -404,16 +404,22 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
         const int nt = env_cus > 0 && env_cus < ncu ? env_cus : ncu / 2;
         std::vector<uint32_t> mt((ncu + 31) / 32, 0u), md((ncu + 31) / 32, 0u);
         for (int c = 0; c < ncu; c++) (c < nt ? mt : md)[c / 32] |= 1u << (c % 32);
-        AIPT_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->st_trace, (uint32_t)mt.size(), mt.data()));
-        AIPT_HIP(ctx, hipExtStreamCreateWithCUMask(&ctx->st_dn, (uint32_t)md.size(), md.data()));
+        if (hipExtStreamCreateWithCUMask(&ctx->st_trace, (uint32_t)mt.size(), mt.data()) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&ctx->st_dn, (uint32_t)md.size(), md.data()) != hipSuccess) {
+            // no CU masks on this runtime: the trace is queued on the context's stream, behind the denoise (never beside it)
+            (void)hipGetLastError();
+            if (ctx->st_trace) hipStreamDestroy(ctx->st_trace);
+            ctx->st_trace = ctx->stream; ctx->st_dn = nullptr;
+        }
     }
     const int back = ctx->front ^ 1;
+    hipStream_t ts = ctx->st_trace;
     // the trace follows everything queued on the context's stream so far except the denoise it is meant to overlap: the
     // denoise that last read the back G-buffer (trace_on_stream orders it behind the previous trace by itself)
-    if (ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->st_trace, ctx->ev_denoised[back], 0));
-    const int rc = aipt::trace_on_stream(ctx, ctx->st_trace, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
+    if (ts != ctx->stream && ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ts, ctx->ev_denoised[back], 0));
+    const int rc = aipt::trace_on_stream(ctx, ts, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
     if (rc) return rc;
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ctx->st_trace));
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ts));
     ctx->pf.valid = true; ctx->pf.cam = *cam; ctx->pf.iter = iter; ctx->pf.depth = depth; ctx->pf.flags = trace_flags;
     ctx->pf.buf = back;
     return AIPT_OK;

@@ -111,7 +111,7 @@ inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     for (hipStream_t ps : ctx->pipe)
         if (e == hipSuccess && ps) e = hipStreamSynchronize(ps);
-    if (e == hipSuccess && ctx->st_trace) e = hipStreamSynchronize(ctx->st_trace);
+    if (e == hipSuccess && ctx->st_trace && ctx->st_trace != ctx->stream) e = hipStreamSynchronize(ctx->st_trace);
     if (e == hipSuccess && ctx->st_dn) e = hipStreamSynchronize(ctx->st_dn);
     return e;
 }

@@ -277,3 +277,44 @@ def test_prefetch_on_disjoint_cus_is_bit_identical_at_a_size_that_overlaps():
         got = run(True)
         for k in range(len(ref)):
             assert np.array_equal(got[k], ref[k]), (rep, k)
+
+
+def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_traces():
+    """Batches of 4+ frames pool their BVH walks (trace_bounce<false,true,true>: lanes refilled from an LDS pool, the walk
+    started without the primitives' distance bound).  The living-room mesh -- diffuse, mirror and glass faces, paths that
+    leave and re-enter the mesh -- traced 8 and 5 frames at a time must equal the frames' own fused-walk traces bit for bit,
+    live counts included."""
+    import torch
+    W, H, depth = 160, 96, 8
+    sc = api.Scene(CORNELL, res=(W, H), depth=depth)
+    first = len(sc.materials)
+    faces, lb, ub, recs = synth.make_living_room_mesh(16384, 565, first_material=first)
+    mats = list(sc.materials) + [api.Material.from_buffer_copy(r) for r in recs]
+    box = api.AABB()
+    box.lb[:] = [float(v) for v in lb]
+    box.ub[:] = [float(v) for v in ub]
+    cams = [sc.orbit(phi=sc.phi + 0.07 * k) for k in range(8)]
+    ctx = api.Context(0)
+    ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
+    g1 = torch.zeros(10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    singles = []
+    for c in cams:
+        ctx.pathtrace(c, 1, depth, g1)
+        ctx.sync()
+        singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy()))
+    assert ctx.trace_kernel_name(1) == "trace_bounce<false,true,false>"
+    ctx.trace_configure_batch(W, H, 8)
+    gb = torch.zeros(8, 10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    for nf in (8, 5):
+        gb.zero_()
+        torch.cuda.synchronize()
+        ctx.pathtrace_batch(cams[:nf], 1, depth, gb)
+        ctx.sync()
+        assert ctx.trace_kernel_name(1) == "trace_bounce<false,true,true>"
+        got = gb.cpu().numpy()
+        for f in range(nf):
+            assert np.array_equal(got[f].view(np.uint32), singles[f][0].view(np.uint32)), (nf, f)
+            assert ctx.live_counts_frame(f, depth).tolist() == singles[f][1].tolist(), (nf, f)
+    ctx.close()

@@ -14,7 +14,7 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
 Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds 32
-consecutive frames.  Their traces share one set of bounce launches per 8 frames (a single 1280x720 frame leaves most of the
+consecutive frames.  Their traces share one set of bounce launches per 16 frames (a single 1280x720 frame leaves most of the
 chip idle in its later bounces; the frames are interleaved pixel by pixel and a workgroup pools the BVH walks of 1024 paths,
 refilling idle lanes).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
 it, so the many small launches of one frame's deep levels run beside the full-size layers of the other; the hidden state is
@@ -76,7 +76,7 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=None,
                     help="trace this many consecutive frames with one set of launches (aipt_frames; bit-identical frames; "
                          "1 = frame by frame, aipt_frame) and run the denoiser passes of consecutive frames on two streams, "
-                         "level by level behind each other.  Default: 32 (traced 8 at a time)")
+                         "level by level behind each other.  Default: 32 (traced 16 at a time)")
     ap.add_argument("--prefetch", action="store_true",
                     help="frame by frame (--batch 1) only: trace frame k+1 while frame k is denoised, the two on disjoint halves "
                          "of the CUs (aipt_frame_prefetch; one frame of latency, same bits)")
@@ -270,7 +270,7 @@ def main():
         nrec = (args.steps + PROF_EVERY - 1) // PROF_EVERY
         ctx.profile_stride(PROF_EVERY)
         ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
-        # batched: every trace call is recorded (a call holds up to 8 frames; an aipt_frames batch is traced in such calls)
+        # batched: every trace call is recorded (a call holds up to 16 frames; an aipt_frames batch is traced in such calls)
         ctx.trace_profile_begin(nrec if B == 1 else (args.steps + 7) // 8 + (args.steps + B - 1) // B + 1, PROF_EVERY if B == 1 else 1)
     barrier()
     t0 = time.perf_counter()

@@ -9,7 +9,7 @@ O=gpurun_out/ev
 rm -rf $O; mkdir -p $O
 B="python bench.py"
 # PMC: the bench command with one denoiser stream, so that a counter belongs to one kernel (two kernels in flight share the
-# chip-wide counters); a bounce launch covers 8 frames either way
+# chip-wide counters); a bounce launch covers 16 frames either way
 P="$B --steps 16 --warmup 8 --no-cpu-baseline --no-roofline-events"
 pass() { tag=$1; shift; AIPT_DN_PIPELINE=0 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- $P > $O/pmc_$tag.log 2>&1; echo "pass $tag rc=$?"; }
 pass fetch FETCH_SIZE

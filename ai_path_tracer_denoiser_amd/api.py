@@ -88,6 +88,7 @@ ABI = [
     ("aipt_frames_gbuffer", C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("aipt_trace_profile_begin", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_trace_profile_end", C.c_int, [_P, _P, C.c_int, C.POINTER(C.c_int)]),
+    ("aipt_trace_profile_calls", C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     ("aipt_trace_kernel_name", C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t]),
     ("aipt_trace_configure", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_trace", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint32, _P, C.c_int, C.c_int]),
@@ -321,6 +322,14 @@ class Context:
         n = C.c_int()
         self._ck(lib().aipt_trace_profile_end(self._h, ms.ctypes.data, nbounces, C.byref(n)))
         return ms, n.value
+
+    def trace_profile_calls(self, nbounces: int, max_calls: int = 4096):
+        """-> (frames held by every recorded trace call [calls], ms of its bounce launches [calls, nbounces]); before _end"""
+        fr = np.zeros(max_calls, np.int32)
+        ms = np.zeros((max_calls, nbounces), np.float64)
+        n = C.c_int()
+        self._ck(lib().aipt_trace_profile_calls(self._h, fr.ctypes.data, ms.ctypes.data, nbounces, max_calls, C.byref(n)))
+        return fr[:n.value].copy(), ms[:n.value].copy()
 
     def trace_kernel_name(self, bounce: int) -> str:
         name = C.create_string_buffer(64)

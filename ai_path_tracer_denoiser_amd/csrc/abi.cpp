@@ -69,6 +69,7 @@ int aipt_create(int device, void* stream, aipt_ctx** out) {
     for (auto& ev : ctx->ev_denoised) hipEventCreateWithFlags(&ev, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_prefetched, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_traced, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_entry, hipEventDisableTiming);
     *out = ctx;
     return AIPT_OK;
 }
@@ -90,6 +91,7 @@ void aipt_destroy(aipt_ctx* ctx) {
     for (auto& ev : ctx->ev_denoised) if (ev) hipEventDestroy(ev);
     if (ctx->ev_prefetched) hipEventDestroy(ctx->ev_prefetched);
     if (ctx->ev_traced) hipEventDestroy(ctx->ev_traced);
+    if (ctx->ev_entry) hipEventDestroy(ctx->ev_entry);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (auto& ev : ctx->fev) if (ev) hipEventDestroy(ev);
@@ -187,6 +189,7 @@ int aipt_frame_configure(aipt_ctx* ctx, int width, int height) {
     ctx->fbatch = 1;
     ctx->d_gbuf = nullptr; ctx->front = 0; ctx->pf.valid = false;
     ctx->denoised_valid[0] = ctx->denoised_valid[1] = false;
+    ctx->denoised_masked[0] = ctx->denoised_masked[1] = false;
     const size_t plane = (size_t)wp * hp;
     // two G-buffers: aipt_frame_prefetch traces the next frame into the back one while the front one is denoised.
     // A miss pixel is all-zero in the reference G-buffer; padding uses the same value and is never overwritten.
@@ -244,6 +247,10 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     // CUs of st_trace) may run beside it; the pass follows the previous denoise (hidden state) and the prefetched trace.
     hipStream_t dn = hit && ctx->st_dn ? ctx->st_dn : ctx->stream;
     if (dn != ctx->stream) {
+        // whatever the host queued on the context's stream before this call (an async read of the previous frame's d_out3 or
+        // G-buffer, say) comes first
+        AIPT_HIP(ctx, hipEventRecord(ctx->ev_entry, ctx->stream));
+        AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_entry, 0));
         AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_prefetched, 0));
         for (int b = 0; b < 2; b++) if (ctx->denoised_valid[b]) AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_denoised[b], 0));
     }
@@ -251,6 +258,7 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
     if (rc) return rc;
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], dn));
     ctx->denoised_valid[ctx->front] = true;
+    ctx->denoised_masked[ctx->front] = dn != ctx->stream;
     if (dn != ctx->stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_denoised[ctx->front], 0));   // join
     if (ctx->frame_timing) {
         AIPT_HIP(ctx, hipEventRecord(ctx->fev[2], ctx->stream));
@@ -289,10 +297,14 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch) {
 static int trace_frames(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
                         float* d_gbatch) {
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
-    for (int k = 0; k < nframes; k += AIPT_TRACE_BATCH_MAX) {
-        const int nb = nframes - k < AIPT_TRACE_BATCH_MAX ? nframes - k : AIPT_TRACE_BATCH_MAX;
+    // as few calls as AIPT_TRACE_BATCH_MAX allows, of (nearly) equal size: 20 frames are traced 10 + 10, not 16 + 4 (the
+    // pooled walks of a 4-frame call refill their lanes from a quarter of the rays)
+    const int ncalls = (nframes + AIPT_TRACE_BATCH_MAX - 1) / AIPT_TRACE_BATCH_MAX;
+    for (int c = 0, k = 0; c < ncalls; c++) {
+        const int nb = nframes / ncalls + (c < nframes % ncalls ? 1 : 0);
         const int rc = aipt::trace_on_stream(ctx, st, cams + k, nb, iter, depth, trace_flags, d_gbatch + k * frame, ctx->fhp, ctx->fwp, frame);
         if (rc) return rc;
+        k += nb;
     }
     return AIPT_OK;
 }
@@ -417,6 +429,10 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     // the trace follows everything queued on the context's stream so far except the denoise it is meant to overlap: the
     // denoise that last read the back G-buffer (trace_on_stream orders it behind the previous trace by itself)
     if (ts != ctx->stream && ctx->denoised_valid[back]) AIPT_HIP(ctx, hipStreamWaitEvent(ts, ctx->ev_denoised[back], 0));
+    // ... and, when the frame being denoised was NOT prefetched (the first frame of a sequence, a changed request), its
+    // denoise runs on the context's stream without a CU mask: the trace may only overlap a denoise on the masked stream
+    if (ts != ctx->stream && ctx->denoised_valid[ctx->front] && !ctx->denoised_masked[ctx->front])
+        AIPT_HIP(ctx, hipStreamWaitEvent(ts, ctx->ev_denoised[ctx->front], 0));
     const int rc = aipt::trace_on_stream(ctx, ts, cam, 1, iter, depth, trace_flags, ctx->d_gbufs[back], ctx->fhp, ctx->fwp, 0);
     if (rc) return rc;
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_prefetched, ts));

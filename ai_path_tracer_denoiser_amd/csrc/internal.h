@@ -51,8 +51,10 @@ struct aipt_ctx {
     hipEvent_t ev_denoised[2] = {nullptr, nullptr};   // last denoise that read d_gbufs[i] has finished
     hipEvent_t ev_prefetched = nullptr;               // the prefetched trace has finished
     hipEvent_t ev_traced = nullptr;                   // last trace (any stream) has finished: traces share one path state
+    hipEvent_t ev_entry = nullptr;                    // aipt_frame: what the host had queued on `stream` before the call
     hipStream_t last_trace_stream = nullptr;
     bool denoised_valid[2] = {false, false};
+    bool denoised_masked[2] = {false, false};         // that denoise ran on the CU-masked stream st_dn (a prefetched frame)
     struct { bool valid = false; aipt_camera cam; int iter = 0, depth = 0; uint32_t flags = 0; int buf = 0; } pf;
     // aipt_frames: a batch of frames traced together, then denoised in order
     int fbatch = 1;

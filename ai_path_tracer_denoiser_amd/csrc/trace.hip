@@ -85,6 +85,7 @@ struct TraceState {
     // HIP-event timing of the bounce launches (aipt_trace_profile_*)
     int prof_max = 0, prof_calls = 0, prof_every = 1, prof_seen = 0;
     std::vector<hipEvent_t> prof_ev;              // [call][bounce][2]
+    std::vector<int> prof_frames;                 // [call] frames the recorded call held
     char kname[2][40] = {};                       // instantiation that ran bounce 0 / the later bounces in the last trace
 };
 
@@ -1171,6 +1172,7 @@ static void free_frame(TraceState* s) {
 static void free_trace_profile(TraceState* s) {
     for (hipEvent_t e : s->prof_ev) if (e) hipEventDestroy(e);
     s->prof_ev.clear();
+    s->prof_frames.clear();
     s->prof_max = 0; s->prof_calls = 0; s->prof_seen = 0;
 }
 
@@ -1562,7 +1564,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     }
     if (cache && iter == 1) s->cache_valid = true;
     if (s->prof_max) {
-        if (prof) s->prof_calls++;
+        if (prof) { s->prof_calls++; s->prof_frames.push_back(nframes); }
         s->prof_seen++;
     }
     AIPT_HIP(ctx, hipGetLastError());
@@ -1603,6 +1605,24 @@ int aipt_trace_profile_end(aipt_ctx* ctx, double* sum_ms_per_bounce, int nbounce
     }
     if (calls) *calls = s->prof_calls;
     free_trace_profile(s);
+    return AIPT_OK;
+}
+
+int aipt_trace_profile_calls(aipt_ctx* ctx, int* nframes_per_call, double* ms_per_call_bounce, int nbounces, int max_calls, int* calls) {
+    AIPT_CHECK_CTX(ctx);
+    TraceState* s = tstate(ctx);
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    const int n = s->prof_calls < max_calls ? s->prof_calls : max_calls;
+    for (int c = 0; c < n; c++) {
+        if (nframes_per_call) nframes_per_call[c] = s->prof_frames[c];
+        for (int b = 0; ms_per_call_bounce && b < nbounces; b++) {
+            float ms = 0;
+            if (b < s->last_depth && b < MAX_DEPTH)
+                AIPT_HIP(ctx, hipEventElapsedTime(&ms, s->prof_ev[((size_t)c * MAX_DEPTH + b) * 2], s->prof_ev[((size_t)c * MAX_DEPTH + b) * 2 + 1]));
+            ms_per_call_bounce[(size_t)c * nbounces + b] = ms;
+        }
+    }
+    if (calls) *calls = n;
     return AIPT_OK;
 }
 

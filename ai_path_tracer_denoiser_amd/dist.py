@@ -101,3 +101,36 @@ def pan_phi(phi0: float, frame: int, period: int = 300, amplitude: float = 0.35)
     """Build-defined orbit pan (the reference's lives on its absent data_gen branch):
     phi_k = phi0 + 0.35 * sin(2*pi*k/300), rounded to fp32 like the reference's float phi."""
     return float(np.float32(phi0 + amplitude * np.sin(2.0 * np.pi * frame / period)))
+
+
+# ---- the multi-GPU run checks itself (SURVEY 8e: "8-GPU result == 1-GPU result per frame") ---------------------------------
+def checksum64(t) -> int:
+    """Position-weighted 64-bit checksum of the bit patterns of a float32 torch tensor (any device).  Integer arithmetic
+    modulo 2^64: the value does not depend on the order a reduction adds in."""
+    import torch
+    bits = t.contiguous().view(torch.int32).flatten().to(torch.int64) & 0xFFFFFFFF
+    w = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+    return int((bits * w).sum().item())
+
+
+def gather_int64(values, device):
+    """all-gather of a short list of int64 per rank -> [world][len(values)] (identity without a process group)"""
+    import torch
+    import torch.distributed as dist
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [mine.cpu().tolist()]
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [o.cpu().tolist() for o in out]
+
+
+def sharded_equals_single(local_sums, rerender, device, rank=0):
+    """Every rank contributes the checksums of the first and the last denoised frame of its chunk (an 8-byte word each, one
+    all-gather); rank 0 renders those frames again by itself -- rerender(r) -> the same checksums for rank r's chunk, computed
+    frame by frame on rank 0's GPU -- and compares.  Returns (all equal, [per-rank equal]) on rank 0, (None, None) elsewhere."""
+    gathered = gather_int64(local_sums, device)
+    if rank != 0:
+        return None, None
+    per_rank = [[int(v) for v in rerender(r)] == [int(v) for v in gathered[r]] for r in range(len(gathered))]
+    return all(per_rank), per_rank

@@ -55,7 +55,7 @@ CONFIGS = {
 }
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
@@ -84,7 +84,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.scene_only:
         args.config = 1
     W, H, depth, kind, ntri, impl = CONFIGS[args.config]
@@ -146,6 +146,101 @@ def build_scene(args, api, synth):
     return blob, cam_bytes, desc
 
 
+class Workload:
+    """Everything bench.py sets up before its timed region, and the calls the timed region makes.  tests/test_gpu_bench_path.py
+    builds the same object, so the parity tests check the path -- and the sizes -- that are timed here."""
+
+    def __init__(self, args, rank=0, world=1, local_rank=0):
+        import numpy as np
+        import torch
+        from ai_path_tracer_denoiser_amd import api, synth
+        from ai_path_tracer_denoiser_amd import dist as adist
+        self.args, self.rank, self.world = args, rank, world
+        self.api, self.adist = api, adist
+        self.dev = torch.device("cuda", local_rank)
+        self.W, self.H, self.depth = args.width, args.height, args.depth
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.ctx = api.Context(local_rank, self.stream.cuda_stream)
+        self.trace_flags = api.TRACE_DEFAULT if args.trace_flags is None else args.trace_flags
+        # ---- rank 0 parses the scene, builds the BVH and makes the weights; one broadcast each (RCCL over xGMI)
+        scene_blob = weight_blob = cam_bytes = desc_b = None
+        if rank == 0:
+            scene_blob, cam_bytes, desc = build_scene(args, api, synth)
+            weight_blob = synth.make_blob(565)
+            desc_b = desc.encode()
+        self.scene_blob = adist.broadcast_bytes(scene_blob, 0, self.dev)
+        self.weight_blob = adist.broadcast_bytes(weight_blob, 0, self.dev)
+        cam_bytes = adist.broadcast_bytes(cam_bytes, 0, self.dev)
+        self.desc = adist.broadcast_bytes(desc_b, 0, self.dev).decode()
+        self.cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
+        self.zoom, self.phi0, self.theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
+        ctx = self.ctx
+        ctx.pathtrace_init_packed(self.scene_blob)   # copies only: the BVH inside the blob was built once, on rank 0
+        ctx.load_weights(self.weight_blob)
+        ctx.frame_configure(self.W, self.H)
+        self.impl = {"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl]
+        ctx.denoise_set_impl(self.impl)
+        self.B = max(1, args.batch)
+        if self.B > 1:
+            ctx.frames_configure(self.B)
+        self.outs = [torch.empty(3, self.H, self.W, device=self.dev) for _ in range(self.B)]
+        self.bn_batch = args.bn == "batch"
+        self.carry = args.hidden == "carry"
+        self.cams = []
+
+    def camera_for(self, g):
+        """camera of GLOBAL frame g of the orbit pan"""
+        cam = self.api.Camera.from_buffer_copy(bytes(self.cam0))
+        self.api.lib().aipt_camera_orbit(cam, self.zoom, self.adist.pan_phi(self.phi0, g), self.theta)
+        return cam
+
+    def set_frames(self, frames):
+        """the global frame indices this rank renders, in order (a contiguous chunk of the sequence)"""
+        self.frames = list(frames)
+        self.cams = [self.camera_for(g) for g in self.frames]
+
+    def trace_call_sizes(self, k0, k1):
+        """frames held by every trace call run_frames(k0, k1) makes (aipt_frames splits a batch evenly over ceil(n/16) calls)"""
+        sizes, k = [], k0
+        while k < k1:
+            nb = min(self.B, k1 - k)
+            nc = (nb + 15) // 16
+            sizes += [nb // nc + (1 if c < nb % nc else 0) for c in range(nc)]
+            k += nb
+        return sizes
+
+    def run_frames(self, k0, k1, on_batch=None):
+        """frames k0 .. k1-1 of this rank, in order; with --batch B the traces of B consecutive frames share their launches.
+        on_batch(k, nb) is called after every call has been queued (tests read the outputs there)."""
+        ctx, B, cams, outs, args = self.ctx, self.B, self.cams, self.outs, self.args
+        k = k0
+        while k < k1:
+            nb = min(B, k1 - k)
+            if nb > 1:
+                ctx.frames(cams[k:k + nb], 1, self.depth, outs[:nb], trace_flags=self.trace_flags, bn_batch=self.bn_batch,
+                           carry_first=self.carry and k > 0, carry=self.carry)
+            else:
+                ctx.frame(cams[k], 1, self.depth, outs[0], trace_flags=self.trace_flags, bn_batch=self.bn_batch,
+                          carry=self.carry and k > 0)
+                # never across the warmup/timed boundary or past the last frame: the timed region holds exactly K traces
+                if args.prefetch and k + 1 < k1:
+                    ctx.frame_prefetch(cams[k + 1], 1, self.depth, self.trace_flags)
+            if on_batch:
+                on_batch(k, nb)
+            k += nb
+
+    def run_frame_by_frame(self, cams, out, on_frame=None, prefetch=False):
+        """the same sequence as unbatched, unpipelined aipt_frame calls from a zero hidden state (the reference's runCuda loop)"""
+        ctx = self.ctx
+        ctx.reset_hidden()
+        for k, c in enumerate(cams):
+            ctx.frame(c, 1, self.depth, out, trace_flags=self.trace_flags, bn_batch=self.bn_batch, carry=self.carry and k > 0)
+            if prefetch and k + 1 < len(cams):
+                ctx.frame_prefetch(cams[k + 1], 1, self.depth, self.trace_flags)
+            if on_frame:
+                on_frame(k)
+
+
 def main():
     args = parse_args()
     respawn_if_needed(args)
@@ -171,61 +266,16 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    W, H, depth = args.width, args.height, args.depth
-    stream = torch.cuda.Stream(device=dev)
-    ctx = api.Context(local_rank, stream.cuda_stream)
-    trace_flags = api.TRACE_DEFAULT if args.trace_flags is None else args.trace_flags
-
-    # ---- rank 0 parses the scene, builds the BVH and makes the weights; one broadcast each (RCCL over xGMI)
-    scene_blob = weight_blob = cam_bytes = desc_b = None
-    if rank == 0:
-        scene_blob, cam_bytes, desc = build_scene(args, api, synth)
-        weight_blob = synth.make_blob(565)
-        desc_b = desc.encode()
-    scene_blob = adist.broadcast_bytes(scene_blob, 0, dev)
-    weight_blob = adist.broadcast_bytes(weight_blob, 0, dev)
-    cam_bytes = adist.broadcast_bytes(cam_bytes, 0, dev)
-    desc = adist.broadcast_bytes(desc_b, 0, dev).decode()
-    cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
-    zoom, phi0, theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
-
-    ctx.pathtrace_init_packed(scene_blob)        # copies only: the BVH inside the blob was built once, on rank 0
-    ctx.load_weights(weight_blob)
-    ctx.frame_configure(W, H)
-    ctx.denoise_set_impl({"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl])
-    B = max(1, args.batch)
-    if B > 1:
-        ctx.frames_configure(B)
-    outs = [torch.empty(3, H, W, device=dev) for _ in range(B)]
-    bn_batch = args.bn == "batch"
-    carry = args.hidden == "carry"
+    wl = Workload(args, rank, world, local_rank)
+    ctx, dev, W, H, depth, B = wl.ctx, wl.dev, wl.W, wl.H, wl.depth, wl.B
+    outs, bn_batch, carry, trace_flags = wl.outs, wl.bn_batch, wl.carry, wl.trace_flags
+    scene_blob, weight_blob, desc = wl.scene_blob, wl.weight_blob, wl.desc
 
     per_rank = args.warmup + args.steps
-    frames = list(adist.frame_shard(rank, world, per_rank))
-
-    def camera_for(g):
-        cam = api.Camera.from_buffer_copy(bytes(cam0))
-        api.lib().aipt_camera_orbit(cam, zoom, adist.pan_phi(phi0, g), theta)
-        return cam
-
-    cams = [camera_for(g) for g in frames]
-
-    def run_frames(k0, k1):
-        """frames k0 .. k1-1 of this rank, in order; with --batch B the traces of B consecutive frames share their launches"""
-        k = k0
-        while k < k1:
-            nb = min(B, k1 - k)
-            if nb > 1:
-                ctx.frames(cams[k:k + nb], 1, depth, outs[:nb], trace_flags=trace_flags, bn_batch=bn_batch,
-                           carry_first=carry and k > 0, carry=carry)
-            else:
-                ctx.frame(cams[k], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry and k > 0)
-                # never across the warmup/timed boundary or past the last frame: the timed region holds exactly K traces
-                if args.prefetch and k + 1 < k1:
-                    ctx.frame_prefetch(cams[k + 1], 1, depth, trace_flags)
-            k += nb
+    wl.set_frames(adist.frame_shard(rank, world, per_rank))
+    cams = wl.cams
+    run_frames = wl.run_frames
 
     def barrier():
         if world > 1:
@@ -266,37 +316,111 @@ def main():
     # other denoiser stream drains before it and resumes after it), so a pair brackets the kernel and not its overlap with
     # the next frame's launches; that costs the first two frames of those batches their overlap (~2 % of `value`).
     PROF_EVERY = B if B >= 16 else 3 * B if B >= 4 else 4
+    timed_trace_calls = wl.trace_call_sizes(args.warmup, per_rank)
     if prof_layers:
         nrec = (args.steps + PROF_EVERY - 1) // PROF_EVERY
         ctx.profile_stride(PROF_EVERY)
         ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
-        # batched: every trace call is recorded (a call holds up to 16 frames; an aipt_frames batch is traced in such calls)
-        ctx.trace_profile_begin(nrec if B == 1 else (args.steps + 7) // 8 + (args.steps + B - 1) // B + 1, PROF_EVERY if B == 1 else 1)
+        # batched: every trace call of the timed region is recorded; frame by frame: every 4th
+        ctx.trace_profile_begin(nrec if B == 1 else len(timed_trace_calls), PROF_EVERY if B == 1 else 1)
     barrier()
     t0 = time.perf_counter()
     run_frames(args.warmup, per_rank)
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed_local = elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n_live = ctx.live_counts(depth)            # of the last trace call (all frames of the last batch together)
+    n_live = ctx.live_counts(depth)            # of the last trace call (all frames of its batch together)
     trace_kernels = [ctx.trace_kernel_name(0), ctx.trace_kernel_name(1)] if depth > 1 else [ctx.trace_kernel_name(0)] * 2
-    # the trace / denoise split: one un-pipelined frame, after the timed region
+    P = W * H
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    # ---- the event recordings are closed BEFORE anything else runs, so that they hold the timed region's launches only
+    conv_prof = trace_prof = None
+    if prof_layers:
+        conv_prof = ctx.profile_end()
+        fr_calls, ms_calls = ctx.trace_profile_calls(depth)
+        ctx.trace_profile_end(depth)
+        trace_prof = (fr_calls, ms_calls)
+    # what the timed region left behind: the last denoised frame and its G-buffer, and the first frame of this rank's chunk
+    ctx.sync()
+    last_nb = (per_rank - args.warmup - 1) % B + 1 if B > 1 else 1     # frames of the last call of the timed region
+    timed_last = outs[last_nb - 1 if B > 1 else 0].clone()
+    gptr, grows, gstride = ctx.gbuffer()
+    timed_gbuf = np.empty((10, grows, gstride), np.float32)
+    assert api.lib().aipt_download(ctx._h, timed_gbuf.ctypes.data, gptr, timed_gbuf.nbytes) == 0
+
+    # ---- validation, outside the timed region: the whole sequence of this rank again, frame by frame (aipt_frame: one trace and
+    # one denoiser pass at a time, no batching, no second stream) from a zero hidden state.  The last frame depends on every
+    # frame before it through the carried hidden state, so equal bits there vouch for the whole batched / pipelined run.  The
+    # same pass gives the frame-by-frame (interactive, no latency) throughput.
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    v0 = time.perf_counter()
+    wl.run_frame_by_frame(cams, outs[0])
+    ctx.sync()
+    fbf_fps = per_rank / (time.perf_counter() - v0)
+    fbf_last = outs[0].clone()
+    fbf_gbuf = np.empty_like(timed_gbuf)
+    gptr2, _, _ = ctx.gbuffer()
+    assert api.lib().aipt_download(ctx._h, fbf_gbuf.ctypes.data, gptr2, fbf_gbuf.nbytes) == 0
+    gbuf_equal = bool(np.array_equal(timed_gbuf.view(np.uint32), fbf_gbuf.view(np.uint32)))
+    out_equal = bool(torch.equal(timed_last.view(torch.int32), fbf_last.view(torch.int32)))
+    validated = gbuf_equal and out_equal
+    # frame by frame with the next frame's trace prefetched on disjoint CUs (one frame of latency); the first pass creates the
+    # two CU-masked streams, the second one is timed
+    wl.run_frame_by_frame(cams[:3], outs[0], prefetch=True)
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    v0 = time.perf_counter()
+    wl.run_frame_by_frame(cams, outs[0], prefetch=True)
+    ctx.sync()
+    fbf_pf_fps = per_rank / (time.perf_counter() - v0)
+    validated = validated and bool(torch.equal(outs[0].view(torch.int32), fbf_last.view(torch.int32)))
+
+    # ---- multi-GPU self-check: every rank's first and last denoised frame, as 8-byte checksums through ONE
+    # all-gather, against rank 0's own frame-by-frame render of those frames (N = 1: rank 0's chunk is the whole sequence)
+    local_sums = [adist.checksum64(timed_last)]
+    # (the first frame of the chunk was overwritten by later batches: its checksum is taken from a re-run of the first
+    # batch-sized call, which is what produced it)
+    ctx.reset_hidden()
+    first_nb = min(B, args.warmup) if args.warmup > 0 else min(B, args.steps)
+    first_sum = {}
+
+    def grab_first(k, nb):
+        if k == 0:
+            ctx.sync()
+            first_sum[0] = adist.checksum64(outs[0])
+    run_frames(0, first_nb, on_batch=grab_first)
+    local_sums.insert(0, first_sum[0])
+
+    def rerender(r):
+        """rank 0 renders rank r's chunk by itself, frame by frame: checksums of its first and last frame"""
+        cs = [wl.camera_for(g) for g in adist.frame_shard(r, world, per_rank)]
+        got = {}
+
+        def on_frame(k):
+            if k == 0 or k == len(cs) - 1:
+                ctx.sync()
+                got[k] = adist.checksum64(outs[0])
+        wl.run_frame_by_frame(cs, outs[0], on_frame=on_frame)
+        return [got[0], got[len(cs) - 1]]
+    sharded_ok, sharded_per_rank = adist.sharded_equals_single(local_sums, rerender, dev, rank)
+    per_rank_fps = adist.gather_int64([int(round(1e3 * args.steps / elapsed_local))], dev)
+
+    # the trace / denoise split: one un-pipelined frame
     ctx.sync()
     ctx.frame_set_timing(True)
     ctx.frame(cams[per_rank - 1], 1, depth, outs[0], trace_flags=trace_flags, bn_batch=bn_batch, carry=carry)
     trace_ms, denoise_ms = ctx.frame_last_times()
-    P = W * H
-    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
 
     roof = other = None
     if prof_layers:
         # ---- conv kernel
-        ms28, ncalls = ctx.profile_end()
+        ms28, ncalls = conv_prof
         launches = ncalls * len(prof_layers)
         tot_ms = float(sum(ms28[l] for l in prof_layers))
         flops_per_frame = sum(layer_tbl[l]["flops"] for l in prof_layers)
@@ -339,26 +463,34 @@ def main():
                      "flops_per_launch": flops_per_frame / len(prof_layers),
                      "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma": mfma, "hbm": hbm,
                      "layers": [arch.layer_table()[l][0] for l in prof_layers]}
-        # ---- bounce kernel (bounces 1 .. depth-1 share one instantiation; bounce 0 is its own)
-        tr_ms, tr_calls = ctx.trace_profile_end(depth)
+        # ---- bounce kernel (bounces 1 .. depth-1 share one instantiation; bounce 0 is its own).  Only the recorded calls that
+        # held the most frequent frame count go into the figure (a timed region of 20 frames is traced 10 + 10, one of 70 frames
+        # 16 + 16 | 14 + 14 | 6): time per launch, frames per launch and bytes per launch then describe the SAME launches.
+        fr_calls, ms_calls = trace_prof
         last_fr = max(1, int(n_live[0]) // P)                                # frames of the last trace call
         nb = [float(v) / last_fr for v in n_live[:depth]]                    # live paths per bounce, per frame
         late = [b for b in range(1, depth) if nb[b] > 0]
         tr_roof = None
-        if tr_calls and late:
-            # every trace call of the timed region is recorded when batched (calls can hold different numbers of frames: the
-            # tail of the sequence), every 4th single-frame call otherwise: times per call, bytes per frame x frames per call
-            fpc = args.steps / tr_calls if B > 1 else 1.0                    # frames per recorded call (mean)
-            t_late = float(sum(tr_ms[b] for b in late)) / tr_calls          # ms per trace call in the later-bounce launches
+        if len(fr_calls) and late:
+            vals, counts = np.unique(fr_calls, return_counts=True)
+            fpc = int(vals[np.argmax(counts * vals)])                        # the frame count that carries most frames
+            sel = fr_calls == fpc
+            nsel = int(sel.sum())
+            t_late = float(ms_calls[sel][:, late].sum()) / nsel             # ms per such call in the later-bounce launches
             by_late = sum(nb[b] * 160.0 for b in late) * fpc                # N_b x 160 B per bounce
-            t_first = float(tr_ms[0]) / tr_calls
+            t_first = float(ms_calls[sel][:, 0].sum()) / nsel
             by_first = (nb[0] * 160.0 + nb[0] * 64.0) * fpc                 # + G-buffer write and image RMW, once per frame
             name = trace_kernels[1]
             g_late = by_late / (t_late * 1e-3) / 1e9 if t_late > 0 else 0.0
+            pm = pmc_entry(name)
+            traffic = pm.get("hbm_bytes_per_launch") if pm and pm.get("frames_per_launch") == fpc else None
             tr_roof = {"bound": "hbm", "achieved": round(g_late, 1), "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
-                       "frac": round(g_late * 1e9 / MI355X_HBM_BPS, 5), "traffic": pmc_traffic(name),
+                       "frac": round(g_late * 1e9 / MI355X_HBM_BPS, 5), "traffic": traffic,
+                       "traffic_note": (None if traffic is not None else
+                                        "the committed PMC pass traced a different number of frames per launch than this run"),
                        "kernel": name, "launches_per_frame": round(len(late) / fpc, 3), "avg_launch_ms": round(t_late / len(late), 5),
-                       "ms_per_frame": round(t_late / fpc, 4), "frames_per_launch": round(fpc, 2), "launches_timed": tr_calls * len(late),
+                       "ms_per_frame": round(t_late / fpc, 4), "frames_per_launch": fpc, "launches_timed": nsel * len(late),
+                       "trace_calls_of_the_timed_region": [int(v) for v in fr_calls],
                        "algorithmic_bytes_per_launch": by_late / len(late),
                        "byte_model": "SURVEY 8d: sum over bounces of N_b x 160 B (44 B state read + 44 B write, 36 B hit record "
                                      "write + read of the reference's layout); BVH and triangle fetches are overhead, not algorithmic",
@@ -366,9 +498,8 @@ def main():
                                         "algorithmic_bytes_per_launch": by_first,
                                         "achieved_GBps": round(by_first / (t_first * 1e-3) / 1e9, 1) if t_first > 0 else 0.0},
                        "rays_per_frame": int(sum(nb)), "grays_per_s": round(sum(nb) * fpc / ((t_late + t_first) * 1e-3) / 1e9, 3),
-                       "note": "latency-bound BVH walk: a launch lasts as long as its slowest wave's chain of dependent node / leaf "
-                               "fetches (tools/trace_stats.py); the HBM roof is reported because north_star asks for it, it is "
-                               "not what bounds this kernel"}
+                       "note": "the pooled BVH walk is VALU-issue-bound (DESIGN.md 5); the HBM roof is reported because north_star "
+                               "asks for it, it is not what bounds this kernel"}
         if tr_roof and tr_roof["ms_per_frame"] > conv_roof["ms_per_frame"]:
             roof, other = tr_roof, conv_roof
         else:
@@ -401,10 +532,29 @@ def main():
                                    f"BN {args.bn}-stats, hidden {args.hidden}, conv {args.impl}",
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
-                       "pipelining": ((f"traces of {B} consecutive frames share their launches and their denoiser passes run on two "
-                                       f"streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else
+                       "pipelining": ((f"throughput mode: a call holds up to {B} consecutive frames; their traces share launches (at most "
+                                       f"16 frames per launch set) and their denoiser passes run on two streams, frame n+1 one encoder "
+                                       f"level behind frame n (aipt_frames)" if B > 1 else
                                       "frame by frame" + ("; the next frame's trace runs beside this frame's denoise on disjoint CUs" if args.prefetch else ""))
                                       + "; frames bit-identical to un-pipelined rendering")},
+            # the mode `value` is quoted in: a batch of frames is in flight together, so the first frame of a call is delivered
+            # after the whole call; the interactive figures (no batching) are under "frame_by_frame"
+            "latency_frames": min(B, args.steps) if B > 1 else (1 if args.prefetch else 0),
+            "frame_by_frame": {"value": round(world * fbf_fps, 3), "unit": "frames/s", "latency_frames": 0,
+                               "prefetch": {"value": round(world * fbf_pf_fps, 3), "latency_frames": 1,
+                                            "note": "aipt_frame_prefetch: frame k+1 traced beside the denoise of frame k on disjoint CUs"},
+                               "note": f"aipt_frame, one call per frame, the {per_rank} frames of this rank's chunk after the timed "
+                                       "region (host-synchronised at the end only)"},
+            "validated": validated,
+            "validation": {"what": "after the timed region the rank's whole sequence is rendered again frame by frame (aipt_frame) from a "
+                                   "zero hidden state; the last timed frame's G-buffer and denoised output must equal it bit for bit "
+                                   "(the hidden state carries every earlier frame into it); the prefetching frame-by-frame run likewise",
+                           "gbuffer_equal": gbuf_equal, "denoised_equal": out_equal},
+            "rccl_ranks": world, "sharded_equals_single": sharded_ok,
+            "sharding_check": {"per_rank_equal": sharded_per_rank,
+                               "per_rank_frames_per_s": [round(v[0] / 1e3, 3) for v in per_rank_fps],
+                               "what": "checksums (8 bytes each, one all-gather) of every rank's first and last denoised frame against "
+                                       "rank 0's own frame-by-frame render of those frames"},
             "roofline": roof,
             "roofline_other": other,
             "cpu_baseline": cpu,
@@ -418,6 +568,15 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_entry(kernel):
+    """the committed rocprofv3 PMC summary of `kernel` (profiles/pmc_dominant.json), or None"""
+    path = os.path.join(ROOT, "profiles", "pmc_dominant.json")
+    try:
+        return json.load(open(path)).get("kernels", {}).get(kernel)
+    except Exception:
+        return None
 
 
 def pmc_traffic(kernel):

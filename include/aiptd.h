@@ -180,6 +180,9 @@ int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n)
  * that ran bounce `bounce` of the last trace, as rocprofv3 names it. */
 int aipt_trace_profile_begin(aipt_ctx* ctx, int max_calls, int every);
 int aipt_trace_profile_end(aipt_ctx* ctx, double* sum_ms_per_bounce, int nbounces, int* calls);
+/* per-call detail of the recorded traces, to be read BEFORE aipt_trace_profile_end (synchronises): call c held
+ * nframes_per_call[c] frames and its bounce-b launch took ms_per_call_bounce[c * nbounces + b]; at most max_calls entries. */
+int aipt_trace_profile_calls(aipt_ctx* ctx, int* nframes_per_call, double* ms_per_call_bounce, int nbounces, int max_calls, int* calls);
 int aipt_trace_kernel_name(aipt_ctx* ctx, int bounce, char* kernel, size_t kernel_len);
 /* BVH-walk statistics accumulated since the last reset, only in a library built with -DAIPT_TRACE_STATS (tools/trace_stats.py;
  * otherwise AIPT_E_STATE): out16 = {lane node visits, wave node-loop trips, lane triangle tests, wave leaf-loop trips, lane leaf

@@ -4,6 +4,7 @@
 // sceneStructs.h) and, on a GPU box, run end to end.
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "pathtrace.h"        // void pathtraceInit(Scene*), pathtraceFree(), pathtrace(uchar4*, int, int)   (pathtrace.h:6-8)
@@ -39,9 +40,22 @@ void pathtrace(uchar4* /*pbo*/, int /*frame*/, int iter) {             // pathtr
     if (rc) { fprintf(stderr, "pathtrace: %s\n", aipt_last_error(g_ctx)); exit(1); }
     // the reference hands the 10-channel tensor to main.cpp through host memory (pathtrace.cu:525); keep that contract
     float* d_gbuf; int rows, stride;
-    aipt_gbuffer(g_ctx, &d_gbuf, &rows, &stride);
-    if (rows == cam.resolution.y && stride == cam.resolution.x)
-        aipt_download(g_ctx, g_scene->state.host_tensor, d_gbuf, sizeof(float) * 10 * rows * stride);
+    if (aipt_gbuffer(g_ctx, &d_gbuf, &rows, &stride)) { fprintf(stderr, "pathtrace: %s\n", aipt_last_error(g_ctx)); exit(1); }
+    const int W = cam.resolution.x, H = cam.resolution.y;
+    int drc;
+    if (rows == H && stride == W) {
+        drc = aipt_download(g_ctx, g_scene->state.host_tensor, d_gbuf, sizeof(float) * 10 * rows * stride);
+    } else {
+        // frame sizes that are not multiples of 32: the device G-buffer is zero-padded at the bottom / right (the reference
+        // model cannot run such frames at all); host_tensor keeps the reference's float[10][H][W]
+        static std::vector<float> padded;
+        padded.resize((size_t)10 * rows * stride);
+        drc = aipt_download(g_ctx, padded.data(), d_gbuf, sizeof(float) * padded.size());
+        for (int c = 0; c < 10 && !drc; c++)
+            for (int y = 0; y < H; y++)
+                memcpy(g_scene->state.host_tensor + ((size_t)c * H + y) * W, padded.data() + ((size_t)c * rows + y) * stride, sizeof(float) * W);
+    }
+    if (drc) { fprintf(stderr, "pathtrace: %s\n", aipt_last_error(g_ctx)); exit(1); }
 }
 
 // main.cpp:101-118 network_prediction_faster_version(float*) becomes a download of the denoised frame, [3][H][W]

@@ -71,3 +71,63 @@ def test_scene_blob_roundtrip_and_pan():
     assert adist.pan_phi(0.0, 300) == pytest.approx(0.0, abs=1e-6)
     # single-process: broadcast is the identity
     assert adist.broadcast_bytes(b"abc", 0, torch.device("cpu")) == b"abc"
+
+
+# ---- the multi-GPU run checks itself: checksums of every rank's first / last frame, one all-gather, rank 0 re-renders ----------
+def _fake_frame(g):
+    """stands in for the denoised frame of global frame g (the CPU tests have no GPU to render one)"""
+    rng = np.random.default_rng(1000 + g)
+    return torch.from_numpy(rng.standard_normal((3, 24, 32)).astype(np.float32))
+
+
+def _check_worker(rank, world, port, q, corrupt_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    per = 6
+    frames = list(adist.frame_shard(rank, world, per))
+    first, last = _fake_frame(frames[0]), _fake_frame(frames[-1])
+    if rank == corrupt_rank:
+        last[1, 2, 3] += 1e-6                                   # one bit pattern off in one rank's last frame
+    local = [adist.checksum64(first), adist.checksum64(last)]
+
+    def rerender(r):
+        fr = list(adist.frame_shard(r, world, per))
+        return [adist.checksum64(_fake_frame(fr[0])), adist.checksum64(_fake_frame(fr[-1]))]
+    ok, per_rank = adist.sharded_equals_single(local, rerender, dev, rank)
+    fps = adist.gather_int64([1000 + rank], dev)
+    q.put((rank, ok, per_rank, fps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("corrupt_rank", [-1, 1])
+def test_sharded_equals_single_world2(corrupt_rank):
+    """bench.py --gpus N / SURVEY 8e: rank 0 learns through ONE all-gather of 8-byte checksums whether every rank's first and
+    last frame equal its own render of them; a single flipped value on one rank is reported for that rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_check_worker, args=(r, 2, port, q, corrupt_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, ok0, per0, fps0), (_, ok1, per1, fps1) = res
+    assert ok1 is None and per1 is None                         # only rank 0 holds the verdict
+    assert fps0 == fps1 == [[1000], [1001]]
+    if corrupt_rank < 0:
+        assert ok0 is True and per0 == [True, True]
+    else:
+        assert ok0 is False and per0 == [True, False]
+
+
+def test_checksum64_is_position_sensitive_and_order_free():
+    a = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+    b = a.clone()
+    b[0, 0], b[0, 1] = a[0, 1], a[0, 0]                         # same multiset of values, different positions
+    assert adist.checksum64(a) == adist.checksum64(a.clone()) != adist.checksum64(b)
+    assert adist.checksum64(torch.tensor([0.0])) != adist.checksum64(torch.tensor([-0.0]))    # bit patterns, not values

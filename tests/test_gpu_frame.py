@@ -127,13 +127,18 @@ def _mesh_scene(res, depth, ntri=4096):
     return sc, mats, faces, box
 
 
-def test_batched_trace_equals_single_frame_traces():
+@pytest.mark.parametrize("mesh", [True, False])
+def test_batched_trace_equals_single_frame_traces(mesh):
     """aipt_trace_batch: frames traced by one set of launches are bit-identical to their own aipt_trace -- G-buffer, live counts
-    per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame)."""
+    per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame).  1 to 16 frames per launch set
+    (16 = the per-frame counters, kernel-argument cameras and the 17-workgroup trace_scan at their limit), on the mesh scene
+    (pooled walks from 4 frames on) and on the primitives-only scene."""
     import torch
     W, H, depth = 100, 60, 6               # 6000 pixels per frame: the frames straddle workgroups and waves
     sc, mats, faces, box = _mesh_scene((W, H), depth)
-    cams = [sc.orbit(phi=sc.phi + 0.15 * k) for k in range(5)]
+    if not mesh:
+        faces, box = faces[:0], None
+    cams = [sc.orbit(phi=sc.phi + 0.15 * k) for k in range(16)]
     fl = api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0
     ctx = api.Context(0)
     ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
@@ -144,10 +149,10 @@ def test_batched_trace_equals_single_frame_traces():
         ctx.pathtrace(c, 1, depth, g1, fl)
         ctx.sync()
         singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy(), ctx.first_hit_materials(W * H).copy()))
-    ctx.trace_configure_batch(W, H, 5)
-    gb = torch.zeros(5, 10, H, W, device="cuda")
+    ctx.trace_configure_batch(W, H, 16)              # AIPT_TRACE_BATCH_MAX: what bench.py's 32-frame calls trace at a time
+    gb = torch.zeros(16, 10, H, W, device="cuda")
     torch.cuda.synchronize()
-    for nf in (5, 3, 1):
+    for nf in (16, 13, 9, 5, 3, 1):
         gb.zero_()
         torch.cuda.synchronize()
         ctx.pathtrace_batch(cams[:nf], 1, depth, gb, fl)
@@ -282,7 +287,7 @@ def test_prefetch_on_disjoint_cus_is_bit_identical_at_a_size_that_overlaps():
 def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_traces():
     """Batches of 4+ frames pool their BVH walks (trace_bounce<false,true,true>: lanes refilled from an LDS pool, the walk
     started without the primitives' distance bound).  The living-room mesh -- diffuse, mirror and glass faces, paths that
-    leave and re-enter the mesh -- traced 8 and 5 frames at a time must equal the frames' own fused-walk traces bit for bit,
+    leave and re-enter the mesh -- traced 16, 13, 9, 8 and 5 frames at a time must equal the frames' own fused-walk traces bit for bit,
     live counts included."""
     import torch
     W, H, depth = 160, 96, 8
@@ -293,7 +298,7 @@ def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_trac
     box = api.AABB()
     box.lb[:] = [float(v) for v in lb]
     box.ub[:] = [float(v) for v in ub]
-    cams = [sc.orbit(phi=sc.phi + 0.07 * k) for k in range(8)]
+    cams = [sc.orbit(phi=sc.phi + 0.07 * k) for k in range(16)]
     ctx = api.Context(0)
     ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
     g1 = torch.zeros(10, H, W, device="cuda")
@@ -304,10 +309,10 @@ def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_trac
         ctx.sync()
         singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy()))
     assert ctx.trace_kernel_name(1) == "trace_bounce<false,true,false>"
-    ctx.trace_configure_batch(W, H, 8)
-    gb = torch.zeros(8, 10, H, W, device="cuda")
+    ctx.trace_configure_batch(W, H, 16)
+    gb = torch.zeros(16, 10, H, W, device="cuda")
     torch.cuda.synchronize()
-    for nf in (8, 5):
+    for nf in (16, 13, 9, 8, 5):
         gb.zero_()
         torch.cuda.synchronize()
         ctx.pathtrace_batch(cams[:nf], 1, depth, gb)
@@ -318,3 +323,45 @@ def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_trac
             assert np.array_equal(got[f].view(np.uint32), singles[f][0].view(np.uint32)), (nf, f)
             assert ctx.live_counts_frame(f, depth).tolist() == singles[f][1].tolist(), (nf, f)
     ctx.close()
+
+
+@pytest.mark.parametrize("mesh", [True, False])
+def test_frame_batches_of_17_to_32_frames_equal_the_frame_by_frame_sequence(mesh):
+    """aipt_frames calls that hold more than one trace launch set (17..32 frames: traced in two calls of nearly equal size)
+    with the hidden state carried from call to call: 32 + 5 frames and 24 + 13 frames, on the mesh scene and on the primitives-
+    only scene, equal 37 aipt_frame calls bit for bit."""
+    import torch
+    W, H, depth = 80, 48, 4
+    sc, mats, faces, box = _mesh_scene((W, H), depth)
+    if not mesh:
+        faces, box = faces[:0], None
+    cams = [sc.orbit(phi=sc.phi + 0.03 * k) for k in range(37)]
+    blob = synth.make_blob(7)
+
+    def run(batch):
+        ctx = api.Context(0)
+        ctx.pathtrace_init(sc.geoms, mats, faces, box)
+        ctx.load_weights(blob)
+        ctx.frame_configure(W, H)
+        outs = []
+        if batch == 1:
+            o = torch.empty(3, H, W, device="cuda")
+            for k, c in enumerate(cams):
+                ctx.frame(c, 1, depth, o, bn_batch=True, carry=k > 0)
+                ctx.sync()
+                outs.append(o.cpu().numpy().copy())
+        else:
+            ctx.frames_configure(batch)
+            ob = [torch.empty(3, H, W, device="cuda") for _ in range(batch)]
+            for k in range(0, len(cams), batch):
+                nb = min(batch, len(cams) - k)
+                ctx.frames(cams[k:k + nb], 1, depth, ob, bn_batch=True, carry_first=k > 0, carry=True)
+                ctx.sync()
+                outs += [ob[j].cpu().numpy().copy() for j in range(nb)]
+        ctx.close()
+        return outs
+    ref = run(1)
+    for batch in (32, 24, 17):
+        got = run(batch)
+        for k in range(len(ref)):
+            assert np.array_equal(got[k], ref[k]), (mesh, batch, k)

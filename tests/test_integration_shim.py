@@ -41,24 +41,31 @@ def test_shim_compiles_and_links_against_the_c_abi(tmp_path):
 
 
 @pytest.mark.gpu
-def test_shim_runs_the_reference_host_loop(tmp_path):
+@pytest.mark.parametrize("res", [(64, 64), (80, 48)])
+def test_shim_runs_the_reference_host_loop(tmp_path, res):
+    """(80, 48) is not a multiple of 32: the device G-buffer is padded to 96 x 64 and the shim hands the reference's
+    float[10][H][W] host_tensor its cropped planes."""
     import oracle
     exe = _build(tmp_path)
     w = tmp_path / "w.aiptw"
     blob = synth.make_blob(565)
     w.write_bytes(blob)
-    scene = tmp_path / "cornell_64.txt"
-    txt = open(os.path.join(ROOT, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         64 64")
-    assert "RES         64 64" in txt
+    scene = tmp_path / "cornell_small.txt"
+    txt = open(os.path.join(ROOT, "scenes", "cornell.txt")).read().replace("RES         800 800", "RES         %d %d" % res)
+    assert "RES         %d %d" % res in txt
     scene.write_text(txt)
     out = tmp_path / "o.f32"
     r = subprocess.run([exe, str(scene), str(w), str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     W, H = [int(v) for v in r.stdout.split()]
+    assert (W, H) == res
     raw = np.fromfile(out, np.float32)
     g, rgb = raw[:10 * W * H].reshape(10, H, W), raw[10 * W * H:].reshape(3, H, W)
     sc = oracle.OracleScene.parse(str(scene))
     g_ref, _, _ = sc.pathtrace()
     assert np.array_equal(g.view(np.uint32), g_ref.view(np.uint32))      # scene->state.host_tensor, the reference's hand-off
-    y_ref = oracle.DenoiseOracle(blob, H, W).forward(g_ref, True, False)
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    gp = np.zeros((10, Hp, Wp), np.float32)
+    gp[:, :H, :W] = g_ref
+    y_ref = oracle.DenoiseOracle(blob, Hp, Wp).forward(gp, True, False)[:, :H, :W]
     assert np.abs(rgb - y_ref).max() <= 1e-3

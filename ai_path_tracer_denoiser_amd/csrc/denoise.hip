@@ -1359,6 +1359,14 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     g.stat = stat; g.sc = DenoiseState::STAT_SC;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
+    // AIPT_DEBUG_LAYER_MASK (tools/coresidency): launch only the conv layers whose bit is set -- the outputs are then garbage;
+    // for bisecting which launch of a forward pass disturbs a kernel running beside it
+    static const unsigned long debug_mask = getenv("AIPT_DEBUG_LAYER_MASK") ? strtoul(getenv("AIPT_DEBUG_LAYER_MASK"), nullptr, 0) : ~0ul;
+    if (!((debug_mask >> li) & 1ul)) {
+        if (batch) dst.bn = BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)};
+        else dst.bn = BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};
+        return AIPT_OK;
+    }
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], s->cur));
     if (s->impl == AIPT_DN_IMPL_VALU) {
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_valu");

@@ -610,9 +610,8 @@ __device__ __forceinline__ void load_leaf_face(const TraceParams& p, int slot, D
 }
 
 // generateRayFromCamera (pathtrace.cu:155-182) for pixel `pix` of frame `fr`
-__device__ __forceinline__ void camera_ray(const TraceParams& p, int pix, int fr, v3& o, v3& d) {
+__device__ __forceinline__ void camera_ray(const TraceParams& p, const aipt_camera& cam, int pix, v3& o, v3& d) {
     const int x = pix % p.W, y = pix / p.W;
-    const aipt_camera& cam = p.cams[fr];
     const v3 view = V(cam.view[0], cam.view[1], cam.view[2]);
     const v3 right = V(cam.right[0], cam.right[1], cam.right[2]);
     const v3 up = V(cam.up[0], cam.up[1], cam.up[2]);
@@ -719,6 +718,13 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     static_assert((MESH && !FIRST) || !POOL, "the pool holds the mesh walks of the later bounces (bounce 0: coherent camera rays)");
     __shared__ int s_wave[4];
     __shared__ int s_pool_n, s_head;
+    // Cameras of the frames traced together.  They arrive as kernel arguments and are read from the kernel-argument segment
+    // with SCALAR loads only (wave-uniform index), then indexed per lane from this LDS copy.  `p.cams[fr]` with a per-lane
+    // frame index compiles to VECTOR loads from the kernel-argument segment (global_load_dwordx4 from kernarg + fr * 84), and
+    // those returned another launch's camera for the last lanes of a wave whenever a conv kernel shared the CU: the runtime
+    // rewrites the same kernel-argument addresses for every launch and nothing keeps the CU's vector L1 coherent with that
+    // (DESIGN.md "Root cause of the round-2 co-residency issue", tools/coresidency/kernarg_vload.hip).
+    __shared__ aipt_camera s_cams[FIRST ? BMAX : 1];
     // dynamic LDS: [MESH: STACK_LDS x 256 stack words][POOL: pool, results][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)],
     // sized by the launch
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
@@ -760,6 +766,11 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
     }
     if (POOL && tid == 0) { s_pool_n = 0; s_head = 0; }
+    if (FIRST) {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);               // provably wave-uniform: p.cams[f] below is s_load
+        for (int f = wv; f < p.nframes; f += 4)
+            if (lane == 0) s_cams[f] = p.cams[f];
+    }
     __syncthreads();
     PHASE(0);
 
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     if (alive) {
         v3 o, d, col;
         if (FIRST) {                                                             // generateRayFromCamera :155-182
-            camera_ray(p, pix, fr, o, d);
+            camera_ray(p, s_cams[FIRST ? fr : 0], pix, o, d);
             col = V(1.0f, 1.0f, 1.0f);
         } else {
             const float4 a = S0[i], b = S1[i], c = S2[i];

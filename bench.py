@@ -150,7 +150,9 @@ class Workload:
     """Everything bench.py sets up before its timed region, and the calls the timed region makes.  tests/test_gpu_bench_path.py
     builds the same object, so the parity tests check the path -- and the sizes -- that are timed here."""
 
-    def __init__(self, args, rank=0, world=1, local_rank=0):
+    def __init__(self, args, rank=0, world=1, local_rank=0, like=None, batch=None):
+        """like: another Workload whose scene / weight blobs and cameras are reused (no second BVH build, no broadcast);
+        batch: override args.batch (1 = a frame-by-frame context: aipt_frame only)"""
         import numpy as np
         import torch
         from ai_path_tracer_denoiser_amd import api, synth
@@ -163,24 +165,28 @@ class Workload:
         self.ctx = api.Context(local_rank, self.stream.cuda_stream)
         self.trace_flags = api.TRACE_DEFAULT if args.trace_flags is None else args.trace_flags
         # ---- rank 0 parses the scene, builds the BVH and makes the weights; one broadcast each (RCCL over xGMI)
-        scene_blob = weight_blob = cam_bytes = desc_b = None
-        if rank == 0:
-            scene_blob, cam_bytes, desc = build_scene(args, api, synth)
-            weight_blob = synth.make_blob(565)
-            desc_b = desc.encode()
-        self.scene_blob = adist.broadcast_bytes(scene_blob, 0, self.dev)
-        self.weight_blob = adist.broadcast_bytes(weight_blob, 0, self.dev)
-        cam_bytes = adist.broadcast_bytes(cam_bytes, 0, self.dev)
-        self.desc = adist.broadcast_bytes(desc_b, 0, self.dev).decode()
-        self.cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
-        self.zoom, self.phi0, self.theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
+        if like is not None:
+            self.scene_blob, self.weight_blob, self.desc = like.scene_blob, like.weight_blob, like.desc
+            self.cam0, self.zoom, self.phi0, self.theta = like.cam0, like.zoom, like.phi0, like.theta
+        else:
+            scene_blob = weight_blob = cam_bytes = desc_b = None
+            if rank == 0:
+                scene_blob, cam_bytes, desc = build_scene(args, api, synth)
+                weight_blob = synth.make_blob(565)
+                desc_b = desc.encode()
+            self.scene_blob = adist.broadcast_bytes(scene_blob, 0, self.dev)
+            self.weight_blob = adist.broadcast_bytes(weight_blob, 0, self.dev)
+            cam_bytes = adist.broadcast_bytes(cam_bytes, 0, self.dev)
+            self.desc = adist.broadcast_bytes(desc_b, 0, self.dev).decode()
+            self.cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
+            self.zoom, self.phi0, self.theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
         ctx = self.ctx
         ctx.pathtrace_init_packed(self.scene_blob)   # copies only: the BVH inside the blob was built once, on rank 0
         ctx.load_weights(self.weight_blob)
         ctx.frame_configure(self.W, self.H)
         self.impl = {"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl]
         ctx.denoise_set_impl(self.impl)
-        self.B = max(1, args.batch)
+        self.B = max(1, args.batch if batch is None else batch)
         if self.B > 1:
             ctx.frames_configure(self.B)
         self.outs = [torch.empty(3, self.H, self.W, device=self.dev) for _ in range(self.B)]
@@ -357,29 +363,33 @@ def main():
     # one denoiser pass at a time, no batching, no second stream) from a zero hidden state.  The last frame depends on every
     # frame before it through the carried hidden state, so equal bits there vouch for the whole batched / pipelined run.  The
     # same pass gives the frame-by-frame (interactive, no latency) throughput.
+    # (a second context, configured for single frames only, on the same stream: what an interactive host would create)
     ctx.sync()
     torch.cuda.synchronize(dev)
+    fb = Workload(args, rank, world, local_rank, like=wl, batch=1) if B > 1 else wl
+    fb.run_frame_by_frame(cams[:2], fb.outs[0])
+    fb.ctx.sync()
     v0 = time.perf_counter()
-    wl.run_frame_by_frame(cams, outs[0])
-    ctx.sync()
+    fb.run_frame_by_frame(cams, fb.outs[0])
+    fb.ctx.sync()
     fbf_fps = per_rank / (time.perf_counter() - v0)
-    fbf_last = outs[0].clone()
+    fbf_last = fb.outs[0].clone()
     fbf_gbuf = np.empty_like(timed_gbuf)
-    gptr2, _, _ = ctx.gbuffer()
-    assert api.lib().aipt_download(ctx._h, fbf_gbuf.ctypes.data, gptr2, fbf_gbuf.nbytes) == 0
+    gptr2, _, _ = fb.ctx.gbuffer()
+    assert api.lib().aipt_download(fb.ctx._h, fbf_gbuf.ctypes.data, gptr2, fbf_gbuf.nbytes) == 0
     gbuf_equal = bool(np.array_equal(timed_gbuf.view(np.uint32), fbf_gbuf.view(np.uint32)))
     out_equal = bool(torch.equal(timed_last.view(torch.int32), fbf_last.view(torch.int32)))
     validated = gbuf_equal and out_equal
     # frame by frame with the next frame's trace prefetched on disjoint CUs (one frame of latency); the first pass creates the
     # two CU-masked streams, the second one is timed
-    wl.run_frame_by_frame(cams[:3], outs[0], prefetch=True)
-    ctx.sync()
+    fb.run_frame_by_frame(cams[:3], fb.outs[0], prefetch=True)
+    fb.ctx.sync()
     torch.cuda.synchronize(dev)
     v0 = time.perf_counter()
-    wl.run_frame_by_frame(cams, outs[0], prefetch=True)
-    ctx.sync()
+    fb.run_frame_by_frame(cams, fb.outs[0], prefetch=True)
+    fb.ctx.sync()
     fbf_pf_fps = per_rank / (time.perf_counter() - v0)
-    validated = validated and bool(torch.equal(outs[0].view(torch.int32), fbf_last.view(torch.int32)))
+    validated = validated and bool(torch.equal(fb.outs[0].view(torch.int32), fbf_last.view(torch.int32)))
 
     # ---- multi-GPU self-check: every rank's first and last denoised frame, as 8-byte checksums through ONE
     # all-gather, against rank 0's own frame-by-frame render of those frames (N = 1: rank 0's chunk is the whole sequence)
@@ -404,9 +414,9 @@ def main():
 
         def on_frame(k):
             if k == 0 or k == len(cs) - 1:
-                ctx.sync()
-                got[k] = adist.checksum64(outs[0])
-        wl.run_frame_by_frame(cs, outs[0], on_frame=on_frame)
+                fb.ctx.sync()
+                got[k] = adist.checksum64(fb.outs[0])
+        fb.run_frame_by_frame(cs, fb.outs[0], on_frame=on_frame)
         return [got[0], got[len(cs) - 1]]
     sharded_ok, sharded_per_rank = adist.sharded_equals_single(local_sums, rerender, dev, rank)
     per_rank_fps = adist.gather_int64([int(round(1e3 * args.steps / elapsed_local))], dev)
@@ -565,6 +575,8 @@ def main():
                       "n_live": [int(v) // last_frames for v in n_live], "n_live_note": "per frame (mean over the last batch)" if last_frames > 1 else "last frame"},
         }
         print(json.dumps(line))
+    if fb is not wl:
+        fb.ctx.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()

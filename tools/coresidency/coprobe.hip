@@ -22,8 +22,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (%s:%d)\n", #e, hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 // ------------------------------------------------------------------------------------------------------------------- victims
-enum { V_DIVSQRT, V_FMA, V_CROSSLANE, V_LDS, V_GATHER, V_SCALAR, V_TRANS, V_BRANCHY, V_COUNT };
-static const char* V_NAME[V_COUNT] = {"divsqrt", "fma", "crosslane", "lds", "gather", "scalar", "trans", "branchy"};
+enum { V_DIVSQRT, V_FMA, V_CROSSLANE, V_LDS, V_GATHER, V_SCALAR, V_TRANS, V_BRANCHY, V_PKF32, V_CAMRAY, V_PKSEL, V_PKSEL_KARG, V_PKSEL_NOLDS, V_COUNT };
+static const char* V_NAME[V_COUNT] = {"divsqrt", "fma", "crosslane", "lds", "gather", "scalar", "trans", "branchy", "pkf32", "camray", "pksel", "pksel_karg", "pksel_nolds"};
 
 __device__ __forceinline__ unsigned hash32(unsigned a) {
     a = (a + 0x7ed55d16u) + (a << 12); a = (a ^ 0xc761c23cu) ^ (a >> 19); a = (a + 0x165667b1u) + (a << 5);
@@ -35,7 +35,7 @@ __device__ __forceinline__ float unit(unsigned h) { return (float)(h >> 8) * (1.
 // every victim: thread t computes a value from hash(t) with `iters` rounds of ONE class of operations and stores it
 template <int KIND>
 __global__ __launch_bounds__(256) void victim(const float4* __restrict__ table, int tmask, float* out, int n, int iters) {
-    __shared__ float s_buf[256 * 4];
+    __shared__ float s_buf[(KIND == V_PKSEL_NOLDS || KIND == V_PKSEL_KARG) ? 1 : 256 * 4];
     const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
     if (t >= n) return;
     unsigned h = hash32((unsigned)t * 2654435761u + 12345u);
@@ -73,6 +73,34 @@ __global__ __launch_bounds__(256) void victim(const float4* __restrict__ table, 
         } else if (KIND == V_TRANS) {               // the transcendental unit alone: v_rcp_f32, v_rsq_f32, v_sqrt_f32 approximations
             const float a = __builtin_amdgcn_rcpf(x), b = __builtin_amdgcn_rsqf(y), c = __builtin_amdgcn_sqrtf(z);
             acc += a + b + c; x = y; y = z; z = 0.25f + 0.5f * (a * b - (float)(int)(a * b));
+        } else if (KIND == V_PKF32) {               // packed fp32: v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 on register pairs
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 a = {x, y}, b = {y, z}, c = {z, x};
+            a = a * b + c;                                                   // (contraction is off: v_pk_mul_f32 + v_pk_add_f32)
+            b = b * (f32x2){-0.5f, 0.75f} + a;
+            c = __builtin_elementwise_fma(a, b, c);                          // v_pk_fma_f32
+            acc += c[0] + c[1];
+            x = 0.25f + 0.5f * (a[0] - (float)(int)a[0]); y = 0.25f + 0.5f * (b[1] - (float)(int)b[1]); z = 0.25f + 0.5f * (c[1] - (float)(int)c[1]);
+        } else if (KIND == V_CAMRAY) {              // trace_bounce's generateRayFromCamera arithmetic (uniform camera in SGPRs, per-lane pixel)
+            const float4 c0 = table[0], c1 = table[1], c2 = table[2];          // wave-uniform: scalar loads (view | up | right + pixel lengths)
+            const int pix = t + it, W = 96;
+            const int px = pix % (W + (tmask & 1) - 1), py = pix / (W + (tmask & 1) - 1);      // run-time divisor, as p.W
+            const float sx = (float)px - 96.0f * 0.5f, sy = (float)py - 64.0f * 0.5f;
+            const float dx = (c0.x - c2.x * c0.w * sx) - c1.x * c1.w * sy;
+            const float dy = (c0.y - c2.y * c0.w * sx) - c1.y * c1.w * sy;
+            const float dz = (c0.z - c2.z * c0.w * sx) - c1.z * c1.w * sy;
+            const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+            acc += dx * inv + (dy * inv) * 2.0f + (dz * inv) * 3.0f;
+        } else if (KIND == V_PKSEL || KIND == V_PKSEL_KARG || KIND == V_PKSEL_NOLDS) {   // packed fp32 with scalar / broadcast operands (op_sel forms) and negation modifiers
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            // wave-uniform -> SGPR operands: from a scalar load of global memory, or (KARG) from kernel arguments
+            const float4 c0 = KIND == V_PKSEL_KARG ? make_float4((float)tmask * (1.0f / 65536.0f), (float)n * (1.0f / 8192.0f), (float)iters * (1.0f / 512.0f), 0.0f) : table[0];
+            f32x2 a = {x, y}, b = {z, x};
+            a = a * (f32x2){c0.x, c0.y} + (f32x2){-0.5f, -0.5f};             // SGPR pair operand, inline-constant broadcast
+            b = b * (f32x2){a[1], a[1]} - a * (f32x2){c0.z, c0.z};           // op_sel broadcast of a high half, SGPR broadcast, negated product
+            a = (f32x2){b[1], b[0]} * a;                                      // swapped halves
+            acc += a[0] - a[1];
+            x = 0.25f + 0.5f * (a[0] - (float)(int)a[0]); y = 0.25f + 0.5f * (b[1] - (float)(int)b[1]); z = 0.25f + 0.5f * (b[0] - (float)(int)b[0]);
         } else {                                    // divergent control flow with per-lane trip counts and EXEC masks
             int trips = 1 + (int)(h & 7u);
             float w = x;
@@ -83,13 +111,34 @@ __global__ __launch_bounds__(256) void victim(const float4* __restrict__ table, 
     out[t] = acc + x;
 }
 
+// The suspect: a struct array passed BY VALUE as a kernel argument and indexed with a per-lane (VGPR) index compiles to VECTOR
+// loads from the kernel-argument segment (global_load from kernarg base + fr * stride), as trace_bounce's p.cams[fr] did.  The
+// host rewrites the argument block for every launch with new values.
+struct KArgs { float cam[16][21]; int n; int pad; float* out; };
+__global__ __launch_bounds__(256) void victim_kernarg(const KArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int fr = t % a.n;                          // a.n == 1 at run time: always 0, but a VGPR to the compiler
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 21; k++) s += a.cam[fr][k] * (float)(k + 1);
+    a.out[t] = s;
+}
+// the same values through scalar loads (wave-uniform index)
+__global__ __launch_bounds__(256) void victim_kernarg_scalar(const KArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 21; k++) s += a.cam[0][k] * (float)(k + 1);
+    a.out[t] = s;
+}
+
 // ------------------------------------------------------------------------------------------------------------------ aggressors
-enum { A_NONE, A_MFMA_F16, A_MFMA_F32, A_MFMA_BF16, A_CVT_DPP, A_LDS_BARRIER, A_VALU, A_STREAM_NT, A_MFMA_F16_LDS, A_COUNT };
-static const char* A_NAME[A_COUNT] = {"none", "mfma_f16", "mfma_f32", "mfma_bf16", "cvt_dpp", "lds62k_barrier", "valu", "stream_nt", "mfma_f16_lds"};
+enum { A_NONE, A_MFMA_F16, A_MFMA_F32, A_MFMA_BF16, A_CVT_DPP, A_LDS_BARRIER, A_VALU, A_STREAM_NT, A_MFMA_F16_LDS, A_PKF32, A_MFMA_F16_PK, A_CONVLIKE, A_MFMA_F16_1ACC, A_COUNT };
+static const char* A_NAME[A_COUNT] = {"none", "mfma_f16", "mfma_f32", "mfma_bf16", "cvt_dpp", "lds62k_barrier", "valu", "stream_nt", "mfma_f16_lds", "pkf32", "mfma_f16_pk", "convlike", "mfma_f16_dep"};
 
 template <int KIND>
 __global__ __launch_bounds__(512, 4) void aggressor(float* sink, const float4* __restrict__ src, size_t nsrc, int iters) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == A_LDS_BARRIER || KIND == A_MFMA_F16_LDS) ? 62080 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(KIND == A_LDS_BARRIER || KIND == A_MFMA_F16_LDS || KIND == A_CONVLIKE) ? 62080 : 16];
     const int tid = threadIdx.x, lane = tid & 63;
     float seed = (float)(tid + 1) * 1e-3f;
     float res = 0.0f;
@@ -154,6 +203,59 @@ __global__ __launch_bounds__(512, 4) void aggressor(float* sink, const float4* _
         float a = seed, b = 0.5f, c = 0.25f;
         for (int it = 0; it < iters * 32; it++) { a = __builtin_fmaf(a, b, c); b = __builtin_fmaf(b, c, a) * 0.5f; c = __builtin_fmaf(c, a, b) * 0.5f; }
         res = a + b + c;
+    } else if (KIND == A_PKF32) {                   // packed fp32 VALU only
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 a = {seed, 0.5f}, b = {0.25f, seed}, c = {0.125f, 0.0625f};
+        for (int it = 0; it < iters * 32; it++) { a = __builtin_elementwise_fma(a, b, c); b = __builtin_elementwise_fma(b, c, a) * (f32x2){0.5f, 0.5f}; c = __builtin_elementwise_fma(c, a, b) * (f32x2){0.5f, 0.5f}; }
+        res = a[0] + b[1] + c[0];
+    } else if (KIND == A_MFMA_F16_PK) {             // f16 MFMAs with packed-fp32 VALU work between them, in the same wave
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f16x8 a, b;
+        for (int k = 0; k < 8; k++) { a[k] = (_Float16)(seed + k * 0.01f); b[k] = (_Float16)(0.5f - k * 0.01f); }
+        f32x16 c0 = {}, c1 = {};
+        f32x2 u = {seed, 0.5f}, v = {0.25f, seed}, w = {0.125f, 0.0625f};
+        for (int it = 0; it < iters * 2; it++) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+            u = __builtin_elementwise_fma(u, v, w); v = __builtin_elementwise_fma(v, w, u) * (f32x2){0.5f, 0.5f};
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+            w = __builtin_elementwise_fma(w, u, v) * (f32x2){0.5f, 0.5f};
+        }
+        res = c0[0] + c1[5] + u[0] + v[1] + w[0];
+    } else if (KIND == A_MFMA_F16_1ACC) {           // dependent f16 MFMAs (one accumulator chain per wave, as the conv's per-row chains)
+        f16x8 a, b;
+        for (int k = 0; k < 8; k++) { a[k] = (_Float16)(seed + k * 0.01f); b[k] = (_Float16)(0.5f - k * 0.01f); }
+        f32x16 c0 = {};
+        for (int it = 0; it < iters * 4; it++) c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+        res = c0[0] + c0[7];
+    } else if (KIND == A_CONVLIKE) {                // the conv's chunk loop in miniature: loads -> pk math + cvt_pkrtz -> ds_write -> barrier -> ds_read_b128 + MFMAs -> barrier
+        f32x16 c0 = {}, c1 = {};
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+        size_t gi = ((size_t)blockIdx.x * 512 + tid) % (nsrc - 8192);
+        for (int it = 0; it < iters; it++) {
+            const f32x4 x = s4[gi], y = s4[gi + 4096];
+            gi = (gi + 512 * 97) % (nsrc - 8192);
+            const f32x4 v = x * seed + y, vs = v * 0.1f;
+            f32x4 m;
+            for (int t = 0; t < 4; t++) m[t] = fmaxf(v[t], vs[t]);
+            const auto h01 = __builtin_amdgcn_cvt_pkrtz(m[0], m[1]);
+            const auto h23 = __builtin_amdgcn_cvt_pkrtz(m[2], m[3]);
+            const f32x4 d = (m - (f32x4){(float)h01[0], (float)h01[1], (float)h23[0], (float)h23[1]}) * 2048.0f;
+            const auto l01 = __builtin_amdgcn_cvt_pkrtz(d[0], d[1]);
+            const auto l23 = __builtin_amdgcn_cvt_pkrtz(d[2], d[3]);
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<f16x4*>(smem + ((tid * 48) % 30720)) = f16x4{(_Float16)h01[0], (_Float16)h01[1], (_Float16)h23[0], (_Float16)h23[1]};
+            *reinterpret_cast<f16x4*>(smem + 30720 + ((tid * 48) % 30720)) = f16x4{(_Float16)l01[0], (_Float16)l01[1], (_Float16)l23[0], (_Float16)l23[1]};
+            __syncthreads();
+            for (int k = 0; k < 4; k++) {
+                const f16x8 a = *reinterpret_cast<const f16x8*>(smem + (((tid + k * 5) * 48) % 30720));
+                const f16x8 b = *reinterpret_cast<const f16x8*>(smem + 30720 + (((tid + k * 7) * 48) % 30720));
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, a, c1, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        res = c0[0] + c1[5];
     } else if (KIND == A_STREAM_NT) {
         const size_t stride = (size_t)gridDim.x * 512;
         float4 s = make_float4(0, 0, 0, 0);
@@ -186,7 +288,7 @@ static void launch_victim(int kind, hipStream_t st, float* out, int n, int iters
     const dim3 grid((n + 255) / 256), blk(256);
     switch (kind) {
 #define VCASE(K) case K: hipLaunchKernelGGL((victim<K>), grid, blk, 0, st, g.table, g.tmask, out, n, iters); break;
-        VCASE(V_DIVSQRT) VCASE(V_FMA) VCASE(V_CROSSLANE) VCASE(V_LDS) VCASE(V_GATHER) VCASE(V_SCALAR) VCASE(V_TRANS) VCASE(V_BRANCHY)
+        VCASE(V_DIVSQRT) VCASE(V_FMA) VCASE(V_CROSSLANE) VCASE(V_LDS) VCASE(V_GATHER) VCASE(V_SCALAR) VCASE(V_TRANS) VCASE(V_BRANCHY) VCASE(V_PKF32) VCASE(V_CAMRAY) VCASE(V_PKSEL) VCASE(V_PKSEL_KARG) VCASE(V_PKSEL_NOLDS)
 #undef VCASE
     }
 }
@@ -194,7 +296,7 @@ static void launch_aggressor(int kind, hipStream_t st, int blocks, int iters) {
     const dim3 grid(blocks), blk(512);
     switch (kind) {
 #define ACASE(K) case K: hipLaunchKernelGGL((aggressor<K>), grid, blk, 0, st, g.sink, g.big, g.nbig, iters); break;
-        ACASE(A_MFMA_F16) ACASE(A_MFMA_F32) ACASE(A_MFMA_BF16) ACASE(A_CVT_DPP) ACASE(A_LDS_BARRIER) ACASE(A_VALU) ACASE(A_STREAM_NT) ACASE(A_MFMA_F16_LDS)
+        ACASE(A_MFMA_F16) ACASE(A_MFMA_F32) ACASE(A_MFMA_BF16) ACASE(A_CVT_DPP) ACASE(A_LDS_BARRIER) ACASE(A_VALU) ACASE(A_STREAM_NT) ACASE(A_MFMA_F16_LDS) ACASE(A_PKF32) ACASE(A_MFMA_F16_PK) ACASE(A_CONVLIKE) ACASE(A_MFMA_F16_1ACC)
 #undef ACASE
         default: break;
     }
@@ -255,6 +357,28 @@ int coprobe_aggressor_launch(int kind, int blocks, int iters, int count, void* s
     for (int k = 0; k < count; k++) launch_aggressor(kind, st, blocks, iters);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
+// one launch of the kernel-argument victim with argument values derived from `seq` (different every launch, as a camera pan);
+// returns the number of threads whose result is not the one THIS launch's arguments give; first[0..1] = first and last bad thread
+int coprobe_kernarg_run(int seq, int scalar, void* stream, int* first_last) {
+    hipStream_t st = stream ? (hipStream_t)stream : g.sv;
+    KArgs a;
+    double want = 0.0;
+    for (int f = 0; f < 16; f++)
+        for (int k = 0; k < 21; k++) a.cam[f][k] = (float)((seq * 7 + f * 3 + k) % 1021) * 0.125f;
+    float w = 0.0f;
+    for (int k = 0; k < 21; k++) w += a.cam[0][k] * (float)(k + 1);      // exact in fp32: small multiples of 1/8
+    (void)want;
+    a.n = 1; a.pad = 0; a.out = g.out;
+    if (scalar) hipLaunchKernelGGL(victim_kernarg_scalar, dim3((g.n + 255) / 256), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(victim_kernarg, dim3((g.n + 255) / 256), dim3(256), 0, st, a);
+    std::vector<float> h(g.n);
+    CK(hipMemcpyAsync(h.data(), g.out, 4 * (size_t)g.n, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    int bad = 0, lo = -1, hi = -1;
+    for (int i = 0; i < g.n; i++) if (h[i] != w) { if (lo < 0) lo = i; hi = i; bad++; }
+    if (first_last) { first_last[0] = lo; first_last[1] = hi; }
+    return bad;
+}
 int coprobe_aggressor_sync(void* stream) { CK(hipStreamSynchronize(stream ? (hipStream_t)stream : g.sa)); return 0; }
 // first differing words of the last run, for the lane pattern: idx[k], got[k], want[k]
 int coprobe_last_diff(int* idx, unsigned* got, unsigned* want, int max) {
@@ -300,6 +424,20 @@ int main(int argc, char** argv) {
             fflush(stdout);
         }
     }
+    for (int scalar = 0; scalar < 2; scalar++)
+        for (int a = 0; a < A_COUNT; a++) {
+            int bad_runs = 0, bad_threads = 0;
+            for (int r = 0; r < runs; r++) {
+                if (a != A_NONE) coprobe_aggressor_launch(a, 2048, 64, 3, nullptr);
+                int fl[2];
+                const int bad = coprobe_kernarg_run(r, scalar, nullptr, fl);
+                if (bad) { if (!bad_runs) printf("   first hit: %d threads, %d..%d (lanes %d..%d)\n", bad, fl[0], fl[1], fl[0] & 63, fl[1] & 63); bad_runs++; bad_threads += bad; }
+                if ((r & 7) == 7) coprobe_aggressor_sync(nullptr);
+            }
+            coprobe_aggressor_sync(nullptr);
+            printf("victim %-10s aggressor %-15s runs %d bad %d (threads %d)\n", scalar ? "karg_sload" : "karg_vload", A_NAME[a], runs, bad_runs, bad_threads);
+            fflush(stdout);
+        }
     return 0;
 }
 #endif

@@ -158,6 +158,25 @@ victims = {}
 for k in range(P.coprobe_victim_count()):
     name = "syn:" + P.coprobe_victim_name(k).decode()
     victims[name] = (lambda kk=k: SynVictim(kk))
+class KernargVictim:
+    """a by-value struct array indexed per lane = vector loads from the kernel-argument segment (what p.cams[fr] compiled to)"""
+
+    def __init__(self, scalar):
+        self.scalar, self.seq = scalar, 0
+        P.coprobe_kernarg_run.argtypes = [C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+
+    def run(self):
+        self.seq += 1
+        fl = (C.c_int * 2)()
+        n = P.coprobe_kernarg_run(self.seq, self.scalar, None, fl)
+        if n and not getattr(self, "said", False):
+            self.said = True
+            print(f"      first hit: {n} threads, {fl[0]}..{fl[1]} (lanes {fl[0] & 63}..{fl[1] & 63})", flush=True)
+        return n
+
+
+victims["syn:kernarg_vload"] = lambda: KernargVictim(0)
+victims["syn:kernarg_sload"] = lambda: KernargVictim(1)
 victims["real:trace_prims_d1"] = lambda: RealTrace(2, 1, False)          # one launch of trace_bounce<true,false,false>, no AA
 victims["real:trace_mesh_d4"] = lambda: RealTrace(3, 4, True)
 victims["torch:divsqrt_chain"] = TorchVictim

@@ -209,9 +209,10 @@ struct Shared {
     aipt_camera cam0;
     float zoom, phi0, theta;
     int W, H, depth;
-    // ranks that SHARE a GPU (--ranks R > --gpus N: the one-GPU check of sharded rendering) take their GPU's lock around
-    // every frame call: a bounce kernel running beside another rank's conv kernels returns wrong values for a few lanes in
-    // a few per cent of the frames (DESIGN.md "Known issue"), so their GPU work never overlaps
+    // ranks that SHARE a GPU (--ranks R > --gpus N: the one-GPU check of sharded rendering) run their frame calls freely beside
+    // each other.  (Round 2 serialised them with a per-GPU lock: a bounce kernel beside another rank's conv kernels returned
+    // wrong values -- packed-fp32 VALU instructions beside gapped fp16 MFMAs; the library no longer contains any.)
+    // AIPTD_GPU_LOCK=1 brings the lock back (A/B of the fix).
     std::mutex* gpu_lock = nullptr;          // [gpus], or nullptr when every rank has its own GPU
 };
 
@@ -446,7 +447,7 @@ int main(int argc, char** argv) {
     // one host thread per rank (SURVEY 8b "Threading": one ctx per GPU, one host thread per ctx)
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::mutex> gpu_locks(o.gpus);
-    if (R > o.gpus) sh.gpu_lock = gpu_locks.data();
+    if (R > o.gpus && getenv("AIPTD_GPU_LOCK") && atoi(getenv("AIPTD_GPU_LOCK"))) sh.gpu_lock = gpu_locks.data();
     if (R == 1) render(sh, ranks[0]);
     else {
         std::vector<std::thread> th;

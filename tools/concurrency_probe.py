@@ -6,15 +6,13 @@ a second context on the same GPU denoises / traces / idles in another host threa
     PROBE_IMPL=0|1|2 (aggressor conv implementation: f32 MFMA, VALU, split-fp16), PROBE_FLAGS (victim AIPT_TRACE_* bits),
     PROBE_DEPTH, PROBE_NOMESH=1, PROBE_LOCK=1 (host calls of the two threads never overlap), PROBE_COMPARE_ON_GPU=1, PROBE_CU_SPLIT=1
 
-Measured (MI355X, ROCm 7.2, round 2): with the split-fp16 conv kernel running beside it, 3-8 % of the traced frames differ
--- runs of 2..16 consecutive lanes ending at a 16-lane boundary get a different hit record / colour -- even for a depth-1,
-no-AA, primitives-only trace (one kernel launch).  0 of 6000 frames beside another trace, a memset loop, the f32-MFMA or
-the VALU conv kernels; the denoiser and torch kernels as victims: 0 of 3000.  Not an out-of-bounds write (1 MiB guard bands
-around every denoiser buffer and sentinel tensors stay intact), not host-side (PROBE_LOCK), not kernarg placement
-(HIP_FORCE_DEV_KERNARG), not a missing wait state or waitcnt (-mllvm -amdgpu-snop-padding / -amdgpu-waitcnt-forcezero
-builds), not dynamic LDS (static variant), not LDS reads in the victim, not the device-to-host copy (PROBE_COMPARE_ON_GPU=1).
-It needs co-residency: PROBE_CU_SPLIT=1 (the two contexts' streams on disjoint halves of the CUs) gives 0 of 1500.
-The library therefore never runs a bounce kernel beside a conv kernel."""
+Round 2 (library built WITH packed fp32): beside the split-fp16 conv kernel 3-8 % of the traced frames differed -- runs of
+consecutive lanes ending at lane 63 of a wave -- even for a depth-1, no-AA, primitives-only trace (one kernel launch); 0 beside
+another trace, a memset loop, the f32-MFMA or the VALU conv kernels.  Round 3 (tools/coresidency/): the victims are the
+packed-fp32 VALU instructions hipcc emitted into the bounce kernels, the aggressor any wave that issues fp16 / bf16 MFMAs with
+gaps between them; reproduced with two synthetic kernels (pk_f32_mfma_erratum.hip).  The library is now built without packed
+fp32 and this probe reports 0 of 6000 without CU masks (gpurun_out/co/orig_probe_nopk.log; AIPT_LIB=<a build with packed fp32>
+brings the failures back)."""
 import sys, os, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

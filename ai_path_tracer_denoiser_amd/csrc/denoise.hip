@@ -481,6 +481,7 @@ struct ConvArgsH {
     // bit for bit, as pooling the normalised tensor, without a pass over it (pool2_norm: 5 launches, 57 us per frame)
     float* pool_out;               // [ceil(cout/4)][H/2][W/2][4] or nullptr
     const float* pool_gamma;       // [cout]
+    int ablate;                    // -DAIPT_CONV_ABLATE builds only (tools/conv_ablate.sh): bit mask of the parts to leave out
 };
 
 template <int RW, int NWV>
@@ -559,6 +560,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
     if (!tile.valid) return;
     CPH_INIT();
+#ifdef AIPT_CONV_ABLATE
+    if (g.ablate & 512) return;    // 256: no BN table of the input, 512: an empty workgroup
+    const int abl = g.ablate;      // 1: no LDS reads + MFMAs, 2: no activation loads, 4: no weight loads, 8: no transform + LDS writes,
+#else                              // 16: no output stores, 32: no BN sums, 64: LDS reads but no MFMAs, 128: no barriers in the chunk loop
+    constexpr int abl = 0;
+#endif
     const int tx0 = tile.tx * 32, ty0 = tile.ty * TH;
     const int n0 = tile.gz * 32;
     const int H = g.H, W = g.W;
@@ -612,6 +619,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 
     f32x4 pa[NU];
     u32x4 pw[NWP];
+#ifdef AIPT_CONV_ABLATE
+#pragma unroll
+    for (int j = 0; j < NU; j++) pa[j] = f32x4{0.5f, 0.25f, 0.125f, 1.0f};
+#pragma unroll
+    for (int j = 0; j < NWP; j++) pw[j] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#endif
     auto fetch = [&](int chunk) {
         const bool fa = chunk < ca16;
         const int cl = fa ? chunk : chunk - ca16;                         // chunk inside its source
@@ -631,17 +644,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                     pa[j][t] = pl[(size_t)ch * plane + (u_off[j] >> 4)];
                 }
             }
-        } else {
+        } else if (!(abl & 2)) {
 #pragma unroll
             for (int j = 0; j < NU; j++) pa[j] = *reinterpret_cast<const f32x4*>(base + (u_off[j] + qo));
         }
         const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
+        if (!(abl & 4)) {
 #pragma unroll
         for (int j = 0; j < NWP; j++)
             if ((j + 1) * NT <= WP || tid + j * NT < WP)      // wave-uniform (WP is a multiple of 64)
                 pw[j] = *reinterpret_cast<const u32x4*>(wsrc + j * NT * 16);
+        }
     };
     auto stash = [&](int chunk) {
+        if (abl & 8) return;
         const float slope = chunk < ca16 ? g.a.slope : g.b.slope;
         const f32x4 ca = *reinterpret_cast<const f32x4*>(tab_a + chunk * KH + q * 4);
         const f32x4 cb = *reinterpret_cast<const f32x4*>(tab_b + chunk * KH + q * 4);
@@ -682,7 +698,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const int c = fa ? kc : kc - ca16 * KH;
         const ConvSrc& s = fa ? g.a : g.b;
         float2 t = make_float2(0.0f, 0.0f);
-        if (c < s.C) t = bn_ab(s.bn, c);
+        if (c < s.C && !(abl & 256)) t = bn_ab(s.bn, c);
         tab_a[kc] = t.x * XS;                                  // (LeakyReLU is positively homogeneous: the scale commutes)
         tab_b[kc] = t.y * XS;
     }
@@ -700,10 +716,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         CPH(3);
         stash(chunk);
         CPH(4);
-        __syncthreads();
+        if (!(abl & 128)) __syncthreads();
         CPH(5);
         if (chunk + 1 < g.nchunks) fetch(chunk + 1);
         CPH(6);
+        if (!(abl & 1)) {
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
             f16x8 fah[RW + 2], fal[RW + 2];
@@ -718,6 +735,13 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 const int boff = ((ky * 3 + kx) * 32 + li) * PXB + lg * 16;
                 const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bhi + boff);
                 const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bhi + Cfg::B_BYTES + boff);
+#ifdef AIPT_CONV_ABLATE
+                if (abl & 64) {                                  // fragments read (and kept alive), nothing multiplied
+#pragma unroll
+                    for (int r = 0; r < RW; r++) asm volatile("" :: "v"(fah[r + ky]), "v"(fal[r + ky]), "v"(fbh), "v"(fbl));
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
 #ifdef AIPT_ONE_ACC
@@ -732,8 +756,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 }
             }
         }
+        }
         CPH(7);
-        __syncthreads();
+        if (!(abl & 128)) __syncthreads();
         CPH(8);
     }
 
@@ -797,7 +822,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                     quad_transpose_dpp(v, lane);
                     const int mi = half * 4 + (lane & 3);
                     const int xp = 4 * (mi >> 1) + 2 * lg + (mi & 1);
-                    if (quad_ok && y < H && tx0 + 2 * xp < W)
+                    if (quad_ok && y < H && tx0 + 2 * xp < W && !(abl & 16))
                         *reinterpret_cast<f32x4*>(prow + xp * 4) = f32x4{v[0], v[1], v[2], v[3]};
                 }
             }
@@ -831,10 +856,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             float v[4] = {t[qq * 4], t[qq * 4 + 1], t[qq * 4 + 2], t[qq * 4 + 3]};
             quad_transpose_dpp(v, lane);
             const int x = tx0 + 8 * qq + 4 * lg + (lane & 3);
-            if (quad_ok && y < H && x < W) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
+            if (quad_ok && y < H && x < W && !(abl & 16)) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
         }
     }
-    if (g.stat) {
+    if (g.stat && !(abl & 32)) {
         float2* red = reinterpret_cast<float2*>(smem);         // [NWV waves][32]; the last loop barrier already passed
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
         if (lg == 0) red[wave * 32 + li] = make_float2(s1, s2);
@@ -850,6 +875,287 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     }
     CPH(9);
     CPH_END();
+}
+
+// -------------------------------------------------------------------------------------------------- split-fp16 conv, persistent + pipelined
+// conv3x3_f16x3p: the same arithmetic, tile (8 rows x 32 pixels x 32 output channels, one row per wave) and operand split as
+// conv3x3_f16x3<1, 8>, restructured around what the round-2 counters showed (MFMA pipe 35 % busy, 43 % of the wave cycles parked
+// at the two barriers of a chunk, a 10 k-cycle prologue per 4-chunk tile):
+//   * PERSISTENT: two workgroups per CU walk their XCD's tiles; the (tile, chunk) pairs of a workgroup form ONE stream of steps,
+//     so the loads of a tile's first chunks are in flight while the previous tile is still being multiplied -- the prologue
+//     latency is paid once per workgroup, not once per tile (the BN table of the input is built once, too);
+//   * TWO LDS STAGES, ONE BARRIER PER STEP: while the MFMAs of step s read stage s & 1, the same waves transform, split and store
+//     step s+1 into the other stage -- one staging unit behind each kx group of nine MFMAs, so every wave's instruction stream
+//     mixes matrix and vector work and no phase leaves the matrix pipe idle;
+//   * activations are fetched a full step ahead of their use into ONE register set (each register is re-issued right after the
+//     unit that consumed it), weights at the top of the step that stores them;
+//   * the images are unpadded (32 bytes per pixel / weight row) and XOR-swizzled, 80 KB for both stages: two workgroups per CU;
+//     a thread stages channel quad (tid & 3) of pixel (tid >> 2) + 128 j, so the 16 lanes of a ds_write_b64 group cover 128
+//     contiguous bytes (conflict-free) and out-of-image pixels are WRITTEN as zeros (no zero-fill pass between tiles);
+//   * BN sums are accumulated as 64-bit fixed point per thread across all tiles of the workgroup: 64 atomics per workgroup instead
+//     of 64 per tile (order-independent as before).
+// Used for the levels with at least 1024 (tile, group) pairs (736 x 1280 and 368 x 640: 85 % of the denoiser's flops).
+constexpr int PC_RS = 34, PC_TH = 8, PC_PL = (PC_TH + 2) * PC_RS;            // 340 halo pixels
+constexpr int PC_A = PC_PL * 32, PC_B = 9 * 32 * 32;                          // bytes of one of hi / lo
+constexpr int PC_STAGE = 2 * PC_A + 2 * PC_B;                                 // 40 192
+static inline size_t convp_lds_bytes(int nchunks) { return 2 * (size_t)PC_STAGE + (size_t)nchunks * KH * 8; }
+
+template <bool W16>
+__global__ __launch_bounds__(512, 4) void conv3x3_f16x3p(const ConvArgsH g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int WP = W16 ? WSLAB / 32 : WSLAB / 16;          // 16-byte weight pieces of a step that are staged
+    constexpr int NWP = (WP + 511) / 512;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lg = lane >> 5;
+    const int nch = g.nchunks, ca16 = g.ca16;
+    float* tab_a = reinterpret_cast<float*>(smem + 2 * PC_STAGE);
+    float* tab_b = tab_a + nch * KH;
+
+    // ---- this workgroup's tiles: XCD b & 7 owns a contiguous range of tiles; its workgroups of channel group gz interleave over it
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
+    const int nw = (int)(gridDim.x >> 3) / groups;
+    const int gz = slot % groups, wsl = slot / groups;
+    const int ntiles = g.tiles_x * g.tiles_y, per = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * per), first = xcd * per + wsl;
+    if (wsl >= nw || first >= t_end) return;
+    const int nitems = (t_end - first + nw - 1) / nw, S = nitems * nch;
+    const int n0 = gz * 32, H = g.H, W = g.W, up = g.a.up;
+    const int sw = up ? (W >> 1) : W;
+    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;      // bytes of one channel quad
+
+    // ---- staging units of this thread: channel quad q of halo pixels p0, p0 + 128, p0 + 256
+    const int q = tid & 3, p0 = tid >> 2;
+    int u_lds[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int pix = p0 + j * 128, yy = pix / PC_RS, xx = pix - yy * PC_RS;
+        u_lds[j] = pix * 32 + ((((q >> 1) ^ (xx >> 3)) & 1) << 4) + ((q & 1) << 3);
+    }
+    const bool u2 = p0 + 256 < PC_PL;                          // the third unit exists for 84 of the 128 pixel slots
+    // weight pieces: piece p -> row p >> 1 (hi rows 0..287, lo rows 288..575), 16-byte half p & 1 (swizzled by the row's bit 3)
+    const int w_lds0 = 2 * PC_A + (tid >> 1) * 32 + ((((tid & 1) ^ (tid >> 4)) & 1) << 4);
+    const unsigned char* wslab = g.wsplit + (size_t)gz * g.wchunks * WSLAB + tid * 16;
+    // MFMA operand addresses: A of halo row (wave + hr), column li + kx; B of weight row tap * 32 + li
+    int a_rd[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) a_rd[kx] = (wave * PC_RS + li + kx) * 32 + (((lg ^ ((li + kx) >> 3)) & 1) << 4);
+    const int b_rd = 2 * PC_A + li * 32 + (((lg ^ (li >> 3)) & 1) << 4);
+
+    // Three cursors walk the steps: MFMA (step s), stash (s + 1), load (s + 2).  The source offsets of the three units belong to
+    // the load cursor's item; the in-image masks are kept for the last two items it entered (slot = item & 1: the stash cursor is
+    // never more than one item behind).
+    unsigned off[3];
+    unsigned mask_e = 0, mask_o = 0;
+    auto setup_item = [&](int item) {
+        const int lin = first + item * nw;
+        const int ty = lin / g.tiles_x, tx = lin - ty * g.tiles_x;
+        unsigned m = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int pix = p0 + j * 128, yy = pix / PC_RS, xx = pix - yy * PC_RS;       // (recomputed per item: registers are scarce)
+            const int y = ty * PC_TH + yy - 1, x = tx * 32 + xx - 1;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W && (j < 2 || u2);
+            m |= in ? (1u << j) : 0u;
+            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
+            off[j] = (unsigned)(up ? (yc >> 1) * sw + (xc >> 1) : yc * sw + xc) * 16u;
+        }
+        if (item & 1) mask_o = m; else mask_e = m;
+    };
+    f32x4 pa[3];
+    u32x4 pw[NWP];
+    auto issue_a = [&](int j, int chunk) {                     // unit j of a step of the load cursor's item (never in a branch)
+        const bool fa = chunk < ca16;
+        const int cl = fa ? chunk : chunk - ca16;
+        const ConvSrc& sr = fa ? g.a : g.b;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(sr.p) + (size_t)cl * 4 * plane16;
+        const int nq = (pad4(sr.C) >> 2) - cl * 4;
+        const unsigned qo = q < nq ? (unsigned)q * plane16 : 0u;               // pad quads re-read quad 0 (their a, b are 0)
+        pa[j] = *reinterpret_cast<const f32x4*>(base + (off[j] + qo));
+    };
+    auto issue_w = [&](int chunk) {
+        const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
+#pragma unroll
+        for (int j = 0; j < NWP; j++) {
+            const bool piece = (j + 1) * 512 <= WP || tid + j * 512 < WP;
+            pw[j] = *reinterpret_cast<const u32x4*>(piece ? wsrc + j * 512 * 16 : wsrc);
+        }
+    };
+    auto stash_a = [&](int j, int chunk, unsigned mask, unsigned char* St) {  // transform + split + store unit j of a step
+        const float slope = chunk < ca16 ? g.a.slope : g.b.slope;
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(tab_a + chunk * KH + q * 4);
+        const f32x4 cb = *reinterpret_cast<const f32x4*>(tab_b + chunk * KH + q * 4);
+        const bool in = (mask >> j) & 1u;
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const float x = fmaf(ca[t], pa[j][t], cb[t]);
+            v[t] = in ? fmaxf(x, x * slope) : 0.0f;            // zero padding in the normalised domain, written (not skipped)
+        }
+        const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
+        const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
+        const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * LO_SCALE, (v[1] - (float)h01[1]) * LO_SCALE));
+        const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * LO_SCALE, (v[3] - (float)h23[1]) * LO_SCALE));
+        if (j < 2 || u2) {
+            *reinterpret_cast<f16x4*>(St + u_lds[j]) = f16x4{h01[0], h01[1], h23[0], h23[1]};
+            *reinterpret_cast<f16x4*>(St + PC_A + u_lds[j]) = f16x4{l01[0], l01[1], l23[0], l23[1]};
+        }
+    };
+    auto stash_w = [&](unsigned char* St) {
+#pragma unroll
+        for (int j = 0; j < NWP; j++)
+            if ((j + 1) * 512 <= WP || tid + j * 512 < WP)
+                *reinterpret_cast<u32x4*>(St + w_lds0 + j * 8192) = pw[j];
+    };
+
+    // ---- prologue: step 0 is loaded, transformed and stored by hand; the activations of step 1 are put in flight
+    int l_item = 0, l_chunk = 0;                               // load cursor
+    auto advance_load = [&]() {                                // to the next step (stays on the last one past the end: dummy re-reads)
+        if (l_item * nch + l_chunk + 1 >= S) return;
+        if (++l_chunk == nch) { l_chunk = 0; l_item++; setup_item(l_item); }
+    };
+    setup_item(0);
+#pragma unroll
+    for (int j = 0; j < 3; j++) issue_a(j, 0);
+    issue_w(0);
+    for (int kc = tid; kc < nch * KH; kc += 512) {             // BN coefficient table over the K16 concat space ((0, 0) for pad channels)
+        const bool fa = kc < ca16 * KH;
+        const int c = fa ? kc : kc - ca16 * KH;
+        const ConvSrc& sr = fa ? g.a : g.b;
+        float2 t = make_float2(0.0f, 0.0f);
+        if (c < sr.C) t = bn_ab(sr.bn, c);
+        tab_a[kc] = t.x * XS;
+        tab_b[kc] = t.y * XS;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 3; j++) stash_a(j, 0, mask_e, smem);
+    stash_w(smem);
+    advance_load();                                            // -> step 1
+#pragma unroll
+    for (int j = 0; j < 3; j++) issue_a(j, l_chunk);
+    const float bj = g.bias[n0 + li];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { acc0[k] = bj; acc1[k] = 0.f; }
+    long long fix1 = 0, fix2 = 0;                              // this thread's BN sums over all its items, 24 fractional bits
+    const int j_out = n0 + li;
+    const bool quad_ok = (j_out & ~3) < g.cout;
+    __syncthreads();
+
+    int m_item = 0, m_chunk = 0;                               // MFMA cursor (step s)
+    int st_item = nch == 1 ? 1 : 0, st_chunk = nch == 1 ? 0 : 1;  // stash cursor (step s + 1)
+    for (int s = 0; s < S; s++) {
+        unsigned char* cur = smem + (s & 1) * PC_STAGE;
+        unsigned char* nxt = smem + ((s + 1) & 1) * PC_STAGE;
+        const bool have_next = s + 1 < S;
+        const int s_chunk = have_next ? st_chunk : m_chunk;
+        const unsigned s_mask = (st_item & 1) ? mask_o : mask_e;
+        issue_w(s_chunk);                                      // weights of step s + 1: stored at the end of this step
+        advance_load();                                        // -> step s + 2: its units are issued below, one behind each kx group
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++) {                   // (fragments are read per tap: 16 live registers instead of 32)
+                const f16x8 fah = *reinterpret_cast<const f16x8*>(cur + a_rd[kx] + ky * PC_RS * 32);
+                const f16x8 fal = *reinterpret_cast<const f16x8*>(cur + a_rd[kx] + ky * PC_RS * 32 + PC_A);
+                const f16x8 fbh = *reinterpret_cast<const f16x8*>(cur + b_rd + (ky * 3 + kx) * 1024);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc0, 0, 0, 0);
+                if (!W16) {
+                    const f16x8 fbl = *reinterpret_cast<const f16x8*>(cur + b_rd + (ky * 3 + kx) * 1024 + PC_B);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc1, 0, 0, 0);
+                }
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc1, 0, 0, 0);
+            }
+            if (have_next) stash_a(kx, s_chunk, s_mask, nxt);  // consumes pa[kx] ...
+            issue_a(kx, l_chunk);                              // ... which is re-issued for step s + 2 (a dummy re-read past the end)
+        }
+        if (have_next) stash_w(nxt);
+
+        if (m_chunk == nch - 1) {
+            // ---- epilogue of item m_item (as conv3x3_f16x3<1, 8>; the BN sums stay in registers)
+            const int lin = first + m_item * nw;
+            const int ty = lin / g.tiles_x, tx = lin - ty * g.tiles_x;
+            const int tx0 = tx * 32, ty0 = ty * PC_TH, y = ty0 + wave;
+            const bool interior = ty0 + PC_TH <= H && tx0 + 32 <= W;
+            f32x16 t = acc0 + acc1 * (1.0f / 2048.0f);
+            if (g.out_lrelu) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
+            }
+            float s1 = 0.f, s2 = 0.f;
+            if (interior) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) { s1 += t[k]; s2 = fmaf(t[k], t[k], s2); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const int x = tx0 + 8 * (k >> 2) + 4 * lg + (k & 3);
+                    const float m = (y < H && x < W) ? t[k] : 0.0f;
+                    s1 += m; s2 = fmaf(m, m, s2);
+                }
+            }
+            fix1 += bn_fix((double)s1); fix2 += bn_fix((double)s2);
+            float* orow = g.out + (((size_t)(j_out >> 2) * H + y) * W + tx0 + 4 * lg + (lane & 3)) * 4;
+#pragma unroll
+            for (int qq = 0; qq < 4; qq++) {
+                float v[4] = {t[qq * 4], t[qq * 4 + 1], t[qq * 4 + 2], t[qq * 4 + 3]};
+                quad_transpose_dpp(v, lane);
+                const int x = tx0 + 8 * qq + 4 * lg + (lane & 3);
+                if (quad_ok && y < H && x < W) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+            if (g.pool_out) {
+                // 2x2 pool of the raw output (see conv3x3_f16x3): vertical pairs are the rows of waves 2v and 2v+1, exchanged through
+                // the stage the MFMAs of this step have just finished with -- fenced by barriers of their own
+                const bool pos = j_out >= g.cout || !(g.pool_gamma[j_out] < 0.0f);
+                float hv[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) hv[m] = pos ? fmaxf(t[2 * m], t[2 * m + 1]) : fminf(t[2 * m], t[2 * m + 1]);
+                float* pbuf = reinterpret_cast<float*>(cur) + (wave >> 1) * 8 * 64;
+                __syncthreads();
+                if (wave & 1) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) pbuf[m * 64 + lane] = hv[m];
+                }
+                __syncthreads();
+                if (!(wave & 1)) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        const float o = pbuf[m * 64 + lane];
+                        hv[m] = pos ? fmaxf(hv[m], o) : fminf(hv[m], o);
+                    }
+                    const int hh = H >> 1, hw = W >> 1;
+                    float* prow = g.pool_out + (((size_t)(j_out >> 2) * hh + (y >> 1)) * hw + (tx0 >> 1)) * 4;
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        float v[4] = {hv[half * 4], hv[half * 4 + 1], hv[half * 4 + 2], hv[half * 4 + 3]};
+                        quad_transpose_dpp(v, lane);
+                        const int mi = half * 4 + (lane & 3);
+                        const int xp = 4 * (mi >> 1) + 2 * lg + (mi & 1);
+                        if (quad_ok && y < H && tx0 + 2 * xp < W)
+                            *reinterpret_cast<f32x4*>(prow + xp * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { acc0[k] = bj; acc1[k] = 0.f; }
+        }
+        m_item = st_item; m_chunk = st_chunk;                  // the cursors move on one step
+        if (++st_chunk == nch) { st_chunk = 0; st_item++; }
+        __syncthreads();
+    }
+    // ---- BN sums of this workgroup: lanes li of both halves and all waves hold fixed-point partials of channel n0 + li
+    if (g.stat) {
+        long long* red = reinterpret_cast<long long*>(smem);   // [8 waves][32][2]; the loop's last barrier has passed
+        fix1 += __shfl_xor(fix1, 32); fix2 += __shfl_xor(fix2, 32);
+        if (lg == 0) { red[(wave * 32 + li) * 2] = fix1; red[(wave * 32 + li) * 2 + 1] = fix2; }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < g.cout) {
+            long long a = 0, c = 0;
+            for (int w = 0; w < 8; w++) { a += red[(w * 32 + tid) * 2]; c += red[(w * 32 + tid) * 2 + 1]; }
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * 2);
+            atomicAdd(dst, (unsigned long long)a);
+            atomicAdd(dst + 1, (unsigned long long)c);
+        }
+    }
 }
 
 // -------------------------------------------------------------------------------------------------- few-output conv
@@ -1287,6 +1593,9 @@ static DenoiseState* state(aipt_ctx* ctx) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->dn->num_cus = prop.multiProcessorCount;
+        // conv3x3_f16x3p declares its LDS at launch: two 40 KB stages + the BN table
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
     }
     return ctx->dn;
 }
@@ -1386,7 +1695,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
-        gh.pool_out = nullptr; gh.pool_gamma = nullptr;
+        gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
@@ -1431,12 +1740,24 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
         gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
+        static const int ablate_env = getenv("AIPT_CONV_ABLATE") ? (int)strtol(getenv("AIPT_CONV_ABLATE"), nullptr, 0) : 0;
+        gh.ablate = ablate_env;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
         f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
-        if (gh.a.planar) {
+        // the two biggest levels (>= 1024 (tile, group) pairs): persistent, continuously pipelined kernel, two workgroups per CU
+        static const int persist_env = getenv("AIPT_F16_PERSIST") ? atoi(getenv("AIPT_F16_PERSIST")) : 0;
+        const int wg_per_xcd = 2 * s->num_cus / 8;
+        const bool persist = persist_env && rows == 8 && nwv == 8 && !gh.a.planar && (long)grid.x * grid.y * grid.z >= 1024 &&
+                             wg_per_xcd / (int)grid.z >= 1 && 2 * convp_lds_bytes(gh.nchunks) <= 160 * 1024;
+        if (persist) {
+            const unsigned pgrid = 8u * (unsigned)(wg_per_xcd / (int)grid.z) * grid.z;
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3p<%s>", w16 ? "true" : "false");
+            if (w16) hipLaunchKernelGGL((conv3x3_f16x3p<true>), dim3(pgrid), dim3(512), convp_lds_bytes(gh.nchunks), s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3p<false>), dim3(pgrid), dim3(512), convp_lds_bytes(gh.nchunks), s->cur, gh);
+        } else if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
             if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
             else hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, s->cur, gh);

@@ -481,6 +481,7 @@ struct ConvArgsH {
     // bit for bit, as pooling the normalised tensor, without a pass over it (pool2_norm: 5 launches, 57 us per frame)
     float* pool_out;               // [ceil(cout/4)][H/2][W/2][4] or nullptr
     const float* pool_gamma;       // [cout]
+    int band;                      // conv3x3_f16x3s: output rows of a strip (band + 2 is a multiple of 3)
     int ablate;                    // -DAIPT_CONV_ABLATE builds only (tools/conv_ablate.sh): bit mask of the parts to leave out
 };
 
@@ -877,283 +878,584 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     CPH_END();
 }
 
-// -------------------------------------------------------------------------------------------------- split-fp16 conv, persistent + pipelined
-// conv3x3_f16x3p: the same arithmetic, tile (8 rows x 32 pixels x 32 output channels, one row per wave) and operand split as
-// conv3x3_f16x3<1, 8>, restructured around what the round-2 counters showed (MFMA pipe 35 % busy, 43 % of the wave cycles parked
-// at the two barriers of a chunk, a 10 k-cycle prologue per 4-chunk tile):
-//   * PERSISTENT: two workgroups per CU walk their XCD's tiles; the (tile, chunk) pairs of a workgroup form ONE stream of steps,
-//     so the loads of a tile's first chunks are in flight while the previous tile is still being multiplied -- the prologue
-//     latency is paid once per workgroup, not once per tile (the BN table of the input is built once, too);
-//   * TWO LDS STAGES, ONE BARRIER PER STEP: while the MFMAs of step s read stage s & 1, the same waves transform, split and store
-//     step s+1 into the other stage -- one staging unit behind each kx group of nine MFMAs, so every wave's instruction stream
-//     mixes matrix and vector work and no phase leaves the matrix pipe idle;
-//   * activations are fetched a full step ahead of their use into ONE register set (each register is re-issued right after the
-//     unit that consumed it), weights at the top of the step that stores them;
-//   * the images are unpadded (32 bytes per pixel / weight row) and XOR-swizzled, 80 KB for both stages: two workgroups per CU;
-//     a thread stages channel quad (tid & 3) of pixel (tid >> 2) + 128 j, so the 16 lanes of a ds_write_b64 group cover 128
-//     contiguous bytes (conflict-free) and out-of-image pixels are WRITTEN as zeros (no zero-fill pass between tiles);
-//   * BN sums are accumulated as 64-bit fixed point per thread across all tiles of the workgroup: 64 atomics per workgroup instead
-//     of 64 per tile (order-independent as before).
-// Used for the levels with at least 1024 (tile, group) pairs (736 x 1280 and 368 x 640: 85 % of the denoiser's flops).
-constexpr int PC_RS = 34, PC_TH = 8, PC_PL = (PC_TH + 2) * PC_RS;            // 340 halo pixels
-constexpr int PC_A = PC_PL * 32, PC_B = 9 * 32 * 32;                          // bytes of one of hi / lo
-constexpr int PC_STAGE = 2 * PC_A + 2 * PC_B;                                 // 40 192
-static inline size_t convp_lds_bytes(int nchunks) { return 2 * (size_t)PC_STAGE + (size_t)nchunks * KH * 8; }
+// -------------------------------------------------------------------------------------------------- split-fp16 conv, register-staged
+// conv3x3_f16x3r: the big levels' kernel.  Same split-fp16 arithmetic as conv3x3_f16x3, a different machine mapping, chosen from
+// the round-3 ablation of that kernel (tools/conv_ablate.sh, profiles/r03_conv_ablate.txt): its parts -- input loads, transform +
+// LDS writes, LDS reads + MFMAs, stores, and a per-workgroup start-up of ~8 k cycles of serial latencies -- ADD UP (128 us on
+// enc1.l2a = 31 floor + 39 loads + 13 staging + 36 MFMA + 10 stores) instead of overlapping: two barrier-phased workgroups per CU
+// march in lockstep, and every tile pays the start-up again.  Here nothing is phased and nothing is paid per tile:
+//   * PERSISTENT, ONE WORKGROUP PER CU, 12 INDEPENDENT WAVES: a wave owns whole items (4 output rows x 30 pixels x 32 output
+//     channels) and never meets a barrier after the prologue; twelve waves per CU at different points of their items overlap loads,
+//     vector work, LDS reads and MFMAs statistically -- what the hardware scheduler is for;
+//   * WEIGHTS RESIDENT IN LDS: the group's hi/lo slabs of ALL chunks (<= 8 x 18 KB) are copied once per workgroup, XOR-swizzled
+//     (conflict-free ds_read_b128); the per-tile 18 KB-per-chunk weight traffic through L1 + LDS writes is gone;
+//   * ACTIVATIONS NEVER TOUCH LDS: in the C4 layout one 16-byte load gives a lane the 4 channels of a pixel, which IS the MFMA
+//     operand layout (lane = pixel, k-group = lane >> 5: 8 channels = two loads); the lane transforms (BN affine, LeakyReLU),
+//     splits into fp16 hi/lo and holds the fragment.  The +-1 column taps are the same registers shifted by one lane (DPP
+//     wave_shr / wave_shl: 8 moves per shift): a wave loads pixels X..X+31 of a halo row and produces outputs X+1..X+30 (the two
+//     edge rows of the 32-row MFMA operand are discarded: 6 % of the MFMA work instead of LDS staging);
+//   * halo row h of an item feeds output rows h-2..h: up to 27 MFMAs (3 column taps x 3 rows x 3 split products) per transformed
+//     row, weights re-read from LDS per row (0.67 ds_read_b128 per MFMA instead of 1.33);
+//   * loads run THREE halo rows ahead of their use through a register ring, across chunk and item boundaries;
+//   * ONE fp32 accumulator per output row (activations x 2^4, weights x 2^7, low halves unscaled: the round-2 -DAIPT_ONE_ACC
+//     arithmetic): 4 rows = 64 VGPRs, three waves per SIMD;
+//   * weights are the MFMA's A operand and activations its B operand, so a lane's accumulators are 16 output channels of ONE
+//     pixel, four consecutive channels per register quad: the C4 store is four plain 16-byte stores (no lane transposes), the
+//     2x2 pool is a register max between rows and one lane shift, and the BN sums are a 5-step butterfly per item kept in a
+//     64-bit fixed-point register pair per lane until the workgroup ends (32 x 2 atomics per workgroup, order-independent).
+constexpr int RR_ROWS = 4, RR_PX = 30;
+constexpr float XS1 = 16.0f, WS1 = 128.0f;
+constexpr int RR_MAXCH = 8;                                   // chunks whose weights fit LDS (fp16-weight mode: twice as many)
+static inline size_t convr_lds_bytes(int nchunks, bool w16) {
+    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * 2 * 8;
+}
 
-template <bool W16>
-__global__ __launch_bounds__(512, 4) void conv3x3_f16x3p(const ConvArgsH g) {
+__device__ __forceinline__ unsigned dpp_wave_shr1(unsigned v) {   // lane i <- lane i - 1
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned dpp_wave_shl1(unsigned v) {   // lane i <- lane i + 1
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);
+}
+// sum over the 32 lanes of a half-wave of 16 per-lane values: a halving butterfly (31 exchanges instead of 80); lane m ends with the
+// total of value k = 8 (m & 1) + 4 (m >> 1 & 1) + 2 (m >> 2 & 1) + (m >> 3 & 1)
+__device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
+    const bool o1 = m & 1, o2 = m & 2, o4 = m & 4, o8 = m & 8;
+    float a8[8], a4[4], a2[2];
+#pragma unroll
+    for (int j = 0; j < 8; j++) a8[j] = (o1 ? s[8 + j] : s[j]) + dpp_xor1(o1 ? s[j] : s[8 + j]);
+#pragma unroll
+    for (int j = 0; j < 4; j++) a4[j] = (o2 ? a8[4 + j] : a8[j]) + dpp_xor2(o2 ? a8[j] : a8[4 + j]);
+#pragma unroll
+    for (int j = 0; j < 2; j++) a2[j] = (o4 ? a4[2 + j] : a4[j]) + __shfl_xor(o4 ? a4[j] : a4[2 + j], 4);
+    float a1 = (o8 ? a2[1] : a2[0]) + __shfl_xor(o8 ? a2[0] : a2[1], 8);
+    a1 += __shfl_xor(a1, 16);
+    return a1;
+}
+
+template <bool W16, int NWV, int PF, bool WC>
+__global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
+    constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
+    static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int WP = W16 ? WSLAB / 32 : WSLAB / 16;          // 16-byte weight pieces of a step that are staged
-    constexpr int NWP = (WP + 511) / 512;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lg = lane >> 5;
-    const int nch = g.nchunks, ca16 = g.ca16;
-    float* tab_a = reinterpret_cast<float*>(smem + 2 * PC_STAGE);
+    constexpr int WB = W16 ? WSLAB / 2 : WSLAB;                // LDS bytes of a chunk's weights
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, gq = lane >> 5;
+    const int nch = g.nchunks, ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up;
+    float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
+    float* bias_s = tab_b + nch * KH;                          // [32], times 2^11: the accumulators start from it
+    long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][2]
 
-    // ---- this workgroup's tiles: XCD b & 7 owns a contiguous range of tiles; its workgroups of channel group gz interleave over it
+    // ---- workgroup -> (XCD, output-channel group); XCD b & 7 owns a contiguous band of item rows
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
-    const int nw = (int)(gridDim.x >> 3) / groups;
-    const int gz = slot % groups, wsl = slot / groups;
-    const int ntiles = g.tiles_x * g.tiles_y, per = (ntiles + 7) >> 3;
-    const int t_end = min(ntiles, (xcd + 1) * per), first = xcd * per + wsl;
-    if (wsl >= nw || first >= t_end) return;
-    const int nitems = (t_end - first + nw - 1) / nw, S = nitems * nch;
-    const int n0 = gz * 32, H = g.H, W = g.W, up = g.a.up;
-    const int sw = up ? (W >> 1) : W;
-    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;      // bytes of one channel quad
+    const int wpg = (int)(gridDim.x >> 3) / groups;            // workgroups per (XCD, group)
+    const int gz = slot % groups, wi = slot / groups;
+    if (wi >= wpg) return;
+    const int n0 = gz * 32;
 
-    // ---- staging units of this thread: channel quad q of halo pixels p0, p0 + 128, p0 + 256
-    const int q = tid & 3, p0 = tid >> 2;
-    int u_lds[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int pix = p0 + j * 128, yy = pix / PC_RS, xx = pix - yy * PC_RS;
-        u_lds[j] = pix * 32 + ((((q >> 1) ^ (xx >> 3)) & 1) << 4) + ((q & 1) << 3);
-    }
-    const bool u2 = p0 + 256 < PC_PL;                          // the third unit exists for 84 of the 128 pixel slots
-    // weight pieces: piece p -> row p >> 1 (hi rows 0..287, lo rows 288..575), 16-byte half p & 1 (swizzled by the row's bit 3)
-    const int w_lds0 = 2 * PC_A + (tid >> 1) * 32 + ((((tid & 1) ^ (tid >> 4)) & 1) << 4);
-    const unsigned char* wslab = g.wsplit + (size_t)gz * g.wchunks * WSLAB + tid * 16;
-    // MFMA operand addresses: A of halo row (wave + hr), column li + kx; B of weight row tap * 32 + li
-    int a_rd[3];
-#pragma unroll
-    for (int kx = 0; kx < 3; kx++) a_rd[kx] = (wave * PC_RS + li + kx) * 32 + (((lg ^ ((li + kx) >> 3)) & 1) << 4);
-    const int b_rd = 2 * PC_A + li * 32 + (((lg ^ (li >> 3)) & 1) << 4);
-
-    // Three cursors walk the steps: MFMA (step s), stash (s + 1), load (s + 2).  The source offsets of the three units belong to
-    // the load cursor's item; the in-image masks are kept for the last two items it entered (slot = item & 1: the stash cursor is
-    // never more than one item behind).
-    unsigned off[3];
-    unsigned mask_e = 0, mask_o = 0;
-    auto setup_item = [&](int item) {
-        const int lin = first + item * nw;
-        const int ty = lin / g.tiles_x, tx = lin - ty * g.tiles_x;
-        unsigned m = 0;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int pix = p0 + j * 128, yy = pix / PC_RS, xx = pix - yy * PC_RS;       // (recomputed per item: registers are scarce)
-            const int y = ty * PC_TH + yy - 1, x = tx * 32 + xx - 1;
-            const bool in = y >= 0 && y < H && x >= 0 && x < W && (j < 2 || u2);
-            m |= in ? (1u << j) : 0u;
-            const int yc = min(max(y, 0), H - 1), xc = min(max(x, 0), W - 1);
-            off[j] = (unsigned)(up ? (yc >> 1) * sw + (xc >> 1) : yc * sw + xc) * 16u;
+    // ---- prologue: weights of all chunks, BN coefficient table, bias -> LDS
+    {
+        const unsigned char* src = g.wsplit + (size_t)gz * g.wchunks * WSLAB;
+        constexpr int PPC = WB / 16;
+        for (int p = tid; p < nch * PPC; p += RR_NT) {
+            const int c = p / PPC, pp = p - c * PPC, row = pp >> 1;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)c * WSLAB + pp * 16);
+            *reinterpret_cast<u32x4*>(smem + c * WB + row * 32 + ((((pp & 1) ^ (row >> 3)) & 1) << 4)) = v;
         }
-        if (item & 1) mask_o = m; else mask_e = m;
+        for (int kc = tid; kc < nch * KH; kc += RR_NT) {
+            const bool fa = kc < ca16 * KH;
+            const int c = fa ? kc : kc - ca16 * KH;
+            const ConvSrc& sr = fa ? g.a : g.b;
+            float2 t = make_float2(0.0f, 0.0f);
+            if (c < sr.C) t = bn_ab(sr.bn, c);
+            tab_a[kc] = t.x * XS1;
+            tab_b[kc] = t.y * XS1;
+        }
+        if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (XS1 * WS1);
+        if (tid < 64) bnacc[tid] = 0;
+    }
+    __syncthreads();
+
+    const int tiles_x = g.tiles_x;
+    const int per = (g.tiles_y + 7) >> 3, rb0 = xcd * per, rb1 = min(g.tiles_y, rb0 + per);
+    const int nitems = max(0, rb1 - rb0) * tiles_x, stride = wpg * RR_WAVES;
+    int it = wave * wpg + wi;                                  // consecutive items go to different workgroups: even load per CU
+    const int sw = up ? (W >> 1) : W;
+    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;
+    const int w_rd = m * 32 + (((gq ^ (m >> 3)) & 1) << 4);
+    // pool: bit k set = register k's channel pools with max (gamma >= 0), else min
+    unsigned posmask = 0xFFFFu;
+    if (g.pool_out) {
+        posmask = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int c = n0 + (k & 3) + 8 * (k >> 2) + 4 * gq;
+            posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
+        }
+    }
+    long long fix1 = 0, fix2 = 0;                              // BN sums of this lane's channel over all items of the wave
+
+    // ---- prefetch cursor: (item, chunk, halo row) three rows ahead of the consumer
+    int pf_it = it, pf_c = 0, pf_y0 = 0;
+    unsigned pf_xo = 0;
+    auto pf_item = [&](int item) {                             // geometry of the cursor's item
+        const int rb = item / tiles_x, tx = item - rb * tiles_x;
+        pf_y0 = (rb0 + rb) * RR_ROWS;
+        const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
+        pf_xo = (unsigned)(up ? (x >> 1) : x) * 16u;
     };
-    f32x4 pa[3];
-    u32x4 pw[NWP];
-    auto issue_a = [&](int j, int chunk) {                     // unit j of a step of the load cursor's item (never in a branch)
-        const bool fa = chunk < ca16;
-        const int cl = fa ? chunk : chunk - ca16;
+    f32x4 raw[PF][2];
+    auto issue = [&](int slot, int hp) {                       // the two channel quads of this lane's pixel in halo row hp
+        const int y = min(max(pf_y0 - 1 + hp, 0), H - 1);
+        const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
+        const bool fa = pf_c < ca16;
+        const int cl = fa ? pf_c : pf_c - ca16;
+        const ConvSrc& sr = fa ? g.a : g.b;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(sr.p) + (size_t)cl * 4 * plane16;
+        const int nq = (pad4(sr.C) >> 2) - cl * 4;             // real quads of this chunk (pad quads re-read quad 0: their a, b are 0)
+        const unsigned q0 = 2 * gq < nq ? (unsigned)(2 * gq) * plane16 : 0u;
+        const unsigned q1 = 2 * gq + 1 < nq ? (unsigned)(2 * gq + 1) * plane16 : 0u;
+        raw[slot][0] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q0));
+        raw[slot][1] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q1));
+    };
+    if (it < nitems) {
+        pf_item(it);
+#pragma unroll
+        for (int h = 0; h < PF; h++) issue(h, h);
+    }
+
+    const int hh = H >> 1, hw = W >> 1;
+    for (; it < nitems; it += stride) {
+        const int rb = it / tiles_x, tx = it - rb * tiles_x;
+        const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
+        const int x = X + m;
+        const bool xin = x >= 0 && x < W;
+        f32x16 acc[RR_ROWS];
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + 8 * j + 4 * gq);
+#pragma unroll
+                for (int r = 0; r < RR_ROWS; r++) { acc[r][4 * j] = bq[0]; acc[r][4 * j + 1] = bq[1]; acc[r][4 * j + 2] = bq[2]; acc[r][4 * j + 3] = bq[3]; }
+            }
+        }
+        for (int c = 0; c < nch; c++) {
+            const float slope = c < ca16 ? g.a.slope : g.b.slope;
+            // the chunk's 18 weight fragments and this lane's 16 BN coefficients stay in registers for its six halo rows
+            const unsigned char* wl = smem + c * WB + w_rd;
+            // (WC; without it they are re-read from LDS where they are used: fewer registers, three waves per SIMD)
+            f16x8 wfh[WC ? 9 : 1], wfl[WC && !W16 ? 9 : 1];
+            const float* ta = tab_a + c * KH + gq * 8;
+            const float* tb = tab_b + c * KH + gq * 8;
+            f32x4 a0, a1, b0, b1;
+            if (WC) {
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    wfh[t] = *reinterpret_cast<const f16x8*>(wl + t * 1024);
+                    if (!W16) wfl[t] = *reinterpret_cast<const f16x8*>(wl + (9 + t) * 1024);
+                }
+                a0 = *reinterpret_cast<const f32x4*>(ta); a1 = *reinterpret_cast<const f32x4*>(ta + 4);
+                b0 = *reinterpret_cast<const f32x4*>(tb); b1 = *reinterpret_cast<const f32x4*>(tb + 4);
+            }
+#pragma unroll
+            for (int h = 0; h < RR_ROWS + 2; h++) {
+                // ---- transform + split this lane's 8 channels of halo row h.  (Nothing of this row may be scheduled above this
+                // point: hipcc otherwise hoists the rows' first FMAs -- and with them the wait for loads issued one row ago.)
+                __builtin_amdgcn_sched_barrier(0);
+                if (!WC) {
+                    a0 = *reinterpret_cast<const f32x4*>(ta); a1 = *reinterpret_cast<const f32x4*>(ta + 4);
+                    b0 = *reinterpret_cast<const f32x4*>(tb); b1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                }
+                const bool ok = xin && (unsigned)(y0 - 1 + h) < (unsigned)H;      // zero padding in the normalised domain
+                unsigned xh[4], xl[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const f32x4& rw = raw[h % PF][p >> 1];
+                    const f32x4& aa = (p >> 1) ? a1 : a0;
+                    const f32x4& bb = (p >> 1) ? b1 : b0;
+                    const int e = (p & 1) * 2;
+                    float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
+                    v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
+                    const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+                    const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1)));
+                    xh[p] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
+                    xl[p] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
+                }
+                // ---- the ring slot is free: fetch PF rows ahead (into the next chunk / the next item when that wraps)
+                if ((h + PF) % (RR_ROWS + 2) == 0) {
+                    if (++pf_c == nch) {
+                        pf_c = 0;
+                        if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }   // (past the end: harmless re-reads)
+                    }
+                }
+                issue(h % PF, (h + PF) % (RR_ROWS + 2));
+                // ---- MFMAs of every (output row, tap row) pair this halo row serves
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    unsigned sh[4], sl[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        sh[p] = kx == 1 ? xh[p] : kx == 0 ? dpp_wave_shr1(xh[p]) : dpp_wave_shl1(xh[p]);
+                        sl[p] = kx == 1 ? xl[p] : kx == 0 ? dpp_wave_shr1(xl[p]) : dpp_wave_shl1(xl[p]);
+                    }
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                    const f16x8 fxh = __builtin_bit_cast(f16x8, (u4){sh[0], sh[1], sh[2], sh[3]});
+                    const f16x8 fxl = __builtin_bit_cast(f16x8, (u4){sl[0], sl[1], sl[2], sl[3]});
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++) {
+                        const int r = h - ky;
+                        if (r < 0 || r >= RR_ROWS) continue;
+                        const f16x8 fwh = WC ? wfh[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, acc[r], 0, 0, 0);
+                        if (!W16) {
+                            const f16x8 fwl = WC ? wfl[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
+                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, acc[r], 0, 0, 0);
+                        }
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue.  D (32 x 32): register k of lane l = channel (k & 3) + 8 (k >> 2) + 4 (l >> 5), pixel l & 31: registers
+        // 4 j .. 4 j + 3 are channel quad 2 j + (l >> 5) of this lane's pixel
+        const bool lane_ok = m >= 1 && m <= RR_PX && x < W;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < RR_ROWS; r++) {
+            acc[r] = acc[r] * (1.0f / (XS1 * WS1));
+            if (g.out_lrelu) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[r][k] = fmaxf(acc[r][k], acc[r][k] * SLOPE);
+            }
+            const int y = y0 + r;
+            if (y < H) {                                       // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 16; k++) { s1[k] += acc[r][k]; s2[k] = fmaf(acc[r][k], acc[r][k], s2[k]); }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int quad = (n0 >> 2) + 2 * j + gq;
+                    if (lane_ok && quad * 4 < g.cout)
+                        *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) =
+                            f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]};
+                }
+            }
+        }
+        if (g.pool_out) {
+            // 2x2 pool of the raw output (see conv3x3_f16x3): rows 2 rp, 2 rp + 1 are registers of this lane, columns x (even: odd
+            // m) and x + 1 are this lane and the next
+#pragma unroll
+            for (int rp = 0; rp < RR_ROWS / 2; rp++) {
+                const int y = y0 + 2 * rp;
+                float pv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const bool pos = (posmask >> k) & 1u;
+                    const float v = pos ? fmaxf(acc[2 * rp][k], acc[2 * rp + 1][k]) : fminf(acc[2 * rp][k], acc[2 * rp + 1][k]);
+                    const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
+                    pv[k] = pos ? fmaxf(v, o) : fminf(v, o);
+                }
+                if (y < H) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int quad = (n0 >> 2) + 2 * j + gq;
+                        if ((m & 1) && m < RR_PX && x < W && quad * 4 < g.cout)
+                            *reinterpret_cast<f32x4*>(g.pool_out + (((size_t)quad * hh + (y >> 1)) * hw + (x >> 1)) * 4) =
+                                f32x4{pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]};
+                    }
+                }
+            }
+        }
+        if (g.stat) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { s1[k] = lane_ok ? s1[k] : 0.f; s2[k] = lane_ok ? s2[k] : 0.f; }
+            fix1 += bn_fix((double)halfwave_sum16(s1, m));
+            fix2 += bn_fix((double)halfwave_sum16(s2, m));
+        }
+    }
+
+    // ---- BN sums of the workgroup: lanes m < 16 of both halves hold channel (k & 3) + 8 (k >> 2) + 4 gq, k as in halfwave_sum16
+    if (g.stat) {
+        if (m < 16) {
+            const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
+            const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)fix1);
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)fix2);
+        }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < g.cout) {
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * 2);
+            atomicAdd(dst, (unsigned long long)bnacc[tid * 2]);
+            atomicAdd(dst + 1, (unsigned long long)bnacc[tid * 2 + 1]);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------- split-fp16 conv, sliding strips
+// conv3x3_f16x3s: conv3x3_f16x3r with the loop nest turned inside out.  A wave owns a STRIP: 30 output columns x a band of BH rows
+// (x 32 output channels), and slides down it: for each halo row, for each 16-channel chunk: load (a register ring, PF steps ahead),
+// transform, split, shift, and 27 MFMAs into the THREE live accumulators (output rows h, h-1, h-2 = tap rows 0, 1, 2).  When a
+// halo row is done, output row h-2 is complete: epilogue of one row (scale, LeakyReLU, C4 stores, pool, BN partial sums), and its
+// accumulator starts the row h+1.  Against the 4-row items of conv3x3_f16x3r:
+//   * every halo row of the strip is loaded and transformed ONCE ((BH+2)/BH instead of 6/4 of the input through L1 and the VALU);
+//   * every step is the full 27 MFMAs; 48 accumulator registers instead of 64; no weight-fragment cache: the chunk loop is
+//     unrolled (NCH is a template parameter) and the 18 fragments of a step are read from LDS where they are used (0.67 reads per
+//     MFMA, LDS 40 % busy at twelve waves) -- 168 VGPRs, THREE waves per SIMD, twelve independent waves per CU;
+//   * one strip per wave and launch where the level allows it (BH is chosen per level so that the strips fill the waves once).
+// BH + 2 is a multiple of 3 (the accumulator that a halo row starts is static: the row loop is unrolled by three).
+template <bool W16, int NCH, int NWV, int PF, bool POOL>
+__global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = NWV * 64;
+    constexpr int WB = W16 ? WSLAB / 2 : WSLAB;
+    static_assert((3 * NCH) % PF == 0, "the ring slot of a step must be static");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, gq = lane >> 5;
+    const int ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up, BH = g.band;
+    float* tab_a = reinterpret_cast<float*>(smem + NCH * WB);
+    float* tab_b = tab_a + NCH * KH;
+    float* bias_s = tab_b + NCH * KH;
+    long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);
+
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
+    const int wpg = (int)(gridDim.x >> 3) / groups;
+    const int gz = slot % groups, wi = slot / groups;
+    if (wi >= wpg) return;
+    const int n0 = gz * 32;
+    {
+        const unsigned char* src = g.wsplit + (size_t)gz * g.wchunks * WSLAB;
+        constexpr int PPC = WB / 16;
+        for (int p = tid; p < NCH * PPC; p += NT) {
+            const int c = p / PPC, pp = p - c * PPC, row = pp >> 1;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)c * WSLAB + pp * 16);
+            *reinterpret_cast<u32x4*>(smem + c * WB + row * 32 + ((((pp & 1) ^ (row >> 3)) & 1) << 4)) = v;
+        }
+        for (int kc = tid; kc < NCH * KH; kc += NT) {
+            const bool fa = kc < ca16 * KH;
+            const int c = fa ? kc : kc - ca16 * KH;
+            const ConvSrc& sr = fa ? g.a : g.b;
+            float2 t = make_float2(0.0f, 0.0f);
+            if (c < sr.C) t = bn_ab(sr.bn, c);
+            tab_a[kc] = t.x * XS1;
+            tab_b[kc] = t.y * XS1;
+        }
+        if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (XS1 * WS1);
+        if (tid < 64) bnacc[tid] = 0;
+    }
+    __syncthreads();
+
+    const int tiles_x = g.tiles_x;
+    const int per = (g.tiles_y + 7) >> 3, bd0 = xcd * per, bd1 = min(g.tiles_y, bd0 + per);
+    const int nunits = max(0, bd1 - bd0) * tiles_x, stride = wpg * NWV;
+    int u = wave * wpg + wi;
+    const int sw = up ? (W >> 1) : W;
+    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;
+    const int w_rd = m * 32 + (((gq ^ (m >> 3)) & 1) << 4);
+    unsigned posmask = 0xFFFFu;
+    if (POOL) {
+        posmask = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int c = n0 + (k & 3) + 8 * (k >> 2) + 4 * gq;
+            posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
+        }
+    }
+    long long fix1 = 0, fix2 = 0;
+    const bool o1 = m & 1, o2 = m & 2;
+
+    // ---- prefetch cursor (unit, halo row, chunk), PF steps ahead of the consumer
+    int pf_u = u, pf_h = 0, pf_c = 0, pf_y0 = 0;
+    unsigned pf_xo = 0;
+    auto pf_unit = [&](int unit) {
+        const int bd = unit / tiles_x, tx = unit - bd * tiles_x;
+        pf_y0 = (bd0 + bd) * BH;
+        const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
+        pf_xo = (unsigned)(up ? (x >> 1) : x) * 16u;
+    };
+    f32x4 raw[PF][2];
+    auto issue = [&](int rs) {                                 // the cursor's step into ring slot rs, then advance the cursor
+        const int y = min(max(pf_y0 - 1 + pf_h, 0), H - 1);
+        const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
+        const bool fa = pf_c < ca16;
+        const int cl = fa ? pf_c : pf_c - ca16;
         const ConvSrc& sr = fa ? g.a : g.b;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(sr.p) + (size_t)cl * 4 * plane16;
         const int nq = (pad4(sr.C) >> 2) - cl * 4;
-        const unsigned qo = q < nq ? (unsigned)q * plane16 : 0u;               // pad quads re-read quad 0 (their a, b are 0)
-        pa[j] = *reinterpret_cast<const f32x4*>(base + (off[j] + qo));
-    };
-    auto issue_w = [&](int chunk) {
-        const unsigned char* wsrc = wslab + (size_t)chunk * WSLAB;
-#pragma unroll
-        for (int j = 0; j < NWP; j++) {
-            const bool piece = (j + 1) * 512 <= WP || tid + j * 512 < WP;
-            pw[j] = *reinterpret_cast<const u32x4*>(piece ? wsrc + j * 512 * 16 : wsrc);
+        const unsigned q0 = 2 * gq < nq ? (unsigned)(2 * gq) * plane16 : 0u;
+        const unsigned q1 = 2 * gq + 1 < nq ? (unsigned)(2 * gq + 1) * plane16 : 0u;
+        raw[rs][0] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q0));
+        raw[rs][1] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q1));
+        if (++pf_c == NCH) {
+            pf_c = 0;
+            if (++pf_h == BH + 2) {
+                pf_h = 0;
+                if (pf_u + stride < nunits) { pf_u += stride; pf_unit(pf_u); }     // (past the end: harmless re-reads)
+            }
         }
     };
-    auto stash_a = [&](int j, int chunk, unsigned mask, unsigned char* St) {  // transform + split + store unit j of a step
-        const float slope = chunk < ca16 ? g.a.slope : g.b.slope;
-        const f32x4 ca = *reinterpret_cast<const f32x4*>(tab_a + chunk * KH + q * 4);
-        const f32x4 cb = *reinterpret_cast<const f32x4*>(tab_b + chunk * KH + q * 4);
-        const bool in = (mask >> j) & 1u;
-        f32x4 v;
+    if (u < nunits) {
+        pf_unit(u);
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const float x = fmaf(ca[t], pa[j][t], cb[t]);
-            v[t] = in ? fmaxf(x, x * slope) : 0.0f;            // zero padding in the normalised domain, written (not skipped)
-        }
-        const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
-        const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
-        const f16x2 l01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[0] - (float)h01[0]) * LO_SCALE, (v[1] - (float)h01[1]) * LO_SCALE));
-        const f16x2 l23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz((v[2] - (float)h23[0]) * LO_SCALE, (v[3] - (float)h23[1]) * LO_SCALE));
-        if (j < 2 || u2) {
-            *reinterpret_cast<f16x4*>(St + u_lds[j]) = f16x4{h01[0], h01[1], h23[0], h23[1]};
-            *reinterpret_cast<f16x4*>(St + PC_A + u_lds[j]) = f16x4{l01[0], l01[1], l23[0], l23[1]};
-        }
-    };
-    auto stash_w = [&](unsigned char* St) {
-#pragma unroll
-        for (int j = 0; j < NWP; j++)
-            if ((j + 1) * 512 <= WP || tid + j * 512 < WP)
-                *reinterpret_cast<u32x4*>(St + w_lds0 + j * 8192) = pw[j];
-    };
-
-    // ---- prologue: step 0 is loaded, transformed and stored by hand; the activations of step 1 are put in flight
-    int l_item = 0, l_chunk = 0;                               // load cursor
-    auto advance_load = [&]() {                                // to the next step (stays on the last one past the end: dummy re-reads)
-        if (l_item * nch + l_chunk + 1 >= S) return;
-        if (++l_chunk == nch) { l_chunk = 0; l_item++; setup_item(l_item); }
-    };
-    setup_item(0);
-#pragma unroll
-    for (int j = 0; j < 3; j++) issue_a(j, 0);
-    issue_w(0);
-    for (int kc = tid; kc < nch * KH; kc += 512) {             // BN coefficient table over the K16 concat space ((0, 0) for pad channels)
-        const bool fa = kc < ca16 * KH;
-        const int c = fa ? kc : kc - ca16 * KH;
-        const ConvSrc& sr = fa ? g.a : g.b;
-        float2 t = make_float2(0.0f, 0.0f);
-        if (c < sr.C) t = bn_ab(sr.bn, c);
-        tab_a[kc] = t.x * XS;
-        tab_b[kc] = t.y * XS;
+        for (int s = 0; s < PF; s++) issue(s);
     }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 3; j++) stash_a(j, 0, mask_e, smem);
-    stash_w(smem);
-    advance_load();                                            // -> step 1
-#pragma unroll
-    for (int j = 0; j < 3; j++) issue_a(j, l_chunk);
-    const float bj = g.bias[n0 + li];
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int k = 0; k < 16; k++) { acc0[k] = bj; acc1[k] = 0.f; }
-    long long fix1 = 0, fix2 = 0;                              // this thread's BN sums over all its items, 24 fractional bits
-    const int j_out = n0 + li;
-    const bool quad_ok = (j_out & ~3) < g.cout;
-    __syncthreads();
 
-    int m_item = 0, m_chunk = 0;                               // MFMA cursor (step s)
-    int st_item = nch == 1 ? 1 : 0, st_chunk = nch == 1 ? 0 : 1;  // stash cursor (step s + 1)
-    for (int s = 0; s < S; s++) {
-        unsigned char* cur = smem + (s & 1) * PC_STAGE;
-        unsigned char* nxt = smem + ((s + 1) & 1) * PC_STAGE;
-        const bool have_next = s + 1 < S;
-        const int s_chunk = have_next ? st_chunk : m_chunk;
-        const unsigned s_mask = (st_item & 1) ? mask_o : mask_e;
-        issue_w(s_chunk);                                      // weights of step s + 1: stored at the end of this step
-        advance_load();                                        // -> step s + 2: its units are issued below, one behind each kx group
+    const int hh = H >> 1, hw = W >> 1;
+    for (; u < nunits; u += stride) {
+        const int bd = u / tiles_x, tx = u - bd * tiles_x;
+        const int y0 = (bd0 + bd) * BH, x = tx * RR_PX - 1 + m;
+        const bool xin = x >= 0 && x < W;
+        const bool lane_ok = m >= 1 && m <= RR_PX && x < W;
+        float s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};     // BN partials of the strip, two butterfly stages in
+        f32x16 acc[3];
+        float prev[POOL ? 16 : 1];
+        for (int h0 = 0; h0 < BH + 2; h0 += 3) {
 #pragma unroll
-        for (int kx = 0; kx < 3; kx++) {
+            for (int j = 0; j < 3; j++) {
+                const int h = h0 + j;
+                // accumulator j starts output row h from the bias
 #pragma unroll
-            for (int ky = 0; ky < 3; ky++) {                   // (fragments are read per tap: 16 live registers instead of 32)
-                const f16x8 fah = *reinterpret_cast<const f16x8*>(cur + a_rd[kx] + ky * PC_RS * 32);
-                const f16x8 fal = *reinterpret_cast<const f16x8*>(cur + a_rd[kx] + ky * PC_RS * 32 + PC_A);
-                const f16x8 fbh = *reinterpret_cast<const f16x8*>(cur + b_rd + (ky * 3 + kx) * 1024);
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc0, 0, 0, 0);
-                if (!W16) {
-                    const f16x8 fbl = *reinterpret_cast<const f16x8*>(cur + b_rd + (ky * 3 + kx) * 1024 + PC_B);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl, acc1, 0, 0, 0);
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + 8 * q + 4 * gq);
+                    acc[j][4 * q] = bq[0]; acc[j][4 * q + 1] = bq[1]; acc[j][4 * q + 2] = bq[2]; acc[j][4 * q + 3] = bq[3];
                 }
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh, acc1, 0, 0, 0);
-            }
-            if (have_next) stash_a(kx, s_chunk, s_mask, nxt);  // consumes pa[kx] ...
-            issue_a(kx, l_chunk);                              // ... which is re-issued for step s + 2 (a dummy re-read past the end)
-        }
-        if (have_next) stash_w(nxt);
-
-        if (m_chunk == nch - 1) {
-            // ---- epilogue of item m_item (as conv3x3_f16x3<1, 8>; the BN sums stay in registers)
-            const int lin = first + m_item * nw;
-            const int ty = lin / g.tiles_x, tx = lin - ty * g.tiles_x;
-            const int tx0 = tx * 32, ty0 = ty * PC_TH, y = ty0 + wave;
-            const bool interior = ty0 + PC_TH <= H && tx0 + 32 <= W;
-            f32x16 t = acc0 + acc1 * (1.0f / 2048.0f);
-            if (g.out_lrelu) {
+                const bool rowin = (unsigned)(y0 - 1 + h) < (unsigned)H;
+                const bool ok = xin && rowin;
 #pragma unroll
-                for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
-            }
-            float s1 = 0.f, s2 = 0.f;
-            if (interior) {
+                for (int c = 0; c < NCH; c++) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int rs = (j * NCH + c) % PF;
+                    const float slope = c < ca16 ? g.a.slope : g.b.slope;
+                    const float* ta = tab_a + c * KH + gq * 8;
+                    const float* tb = tab_b + c * KH + gq * 8;
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ta), a1 = *reinterpret_cast<const f32x4*>(ta + 4);
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb), b1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                    unsigned xh[4], xl[4];
 #pragma unroll
-                for (int k = 0; k < 16; k++) { s1 += t[k]; s2 = fmaf(t[k], t[k], s2); }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const int x = tx0 + 8 * (k >> 2) + 4 * lg + (k & 3);
-                    const float m = (y < H && x < W) ? t[k] : 0.0f;
-                    s1 += m; s2 = fmaf(m, m, s2);
-                }
-            }
-            fix1 += bn_fix((double)s1); fix2 += bn_fix((double)s2);
-            float* orow = g.out + (((size_t)(j_out >> 2) * H + y) * W + tx0 + 4 * lg + (lane & 3)) * 4;
-#pragma unroll
-            for (int qq = 0; qq < 4; qq++) {
-                float v[4] = {t[qq * 4], t[qq * 4 + 1], t[qq * 4 + 2], t[qq * 4 + 3]};
-                quad_transpose_dpp(v, lane);
-                const int x = tx0 + 8 * qq + 4 * lg + (lane & 3);
-                if (quad_ok && y < H && x < W) *reinterpret_cast<f32x4*>(orow + 32 * qq) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-            if (g.pool_out) {
-                // 2x2 pool of the raw output (see conv3x3_f16x3): vertical pairs are the rows of waves 2v and 2v+1, exchanged through
-                // the stage the MFMAs of this step have just finished with -- fenced by barriers of their own
-                const bool pos = j_out >= g.cout || !(g.pool_gamma[j_out] < 0.0f);
-                float hv[8];
-#pragma unroll
-                for (int m = 0; m < 8; m++) hv[m] = pos ? fmaxf(t[2 * m], t[2 * m + 1]) : fminf(t[2 * m], t[2 * m + 1]);
-                float* pbuf = reinterpret_cast<float*>(cur) + (wave >> 1) * 8 * 64;
-                __syncthreads();
-                if (wave & 1) {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) pbuf[m * 64 + lane] = hv[m];
-                }
-                __syncthreads();
-                if (!(wave & 1)) {
-#pragma unroll
-                    for (int m = 0; m < 8; m++) {
-                        const float o = pbuf[m * 64 + lane];
-                        hv[m] = pos ? fmaxf(hv[m], o) : fminf(hv[m], o);
+                    for (int p = 0; p < 4; p++) {
+                        const f32x4& rw = raw[rs][p >> 1];
+                        const f32x4& aa = (p >> 1) ? a1 : a0;
+                        const f32x4& bb = (p >> 1) ? b1 : b0;
+                        const int e = (p & 1) * 2;
+                        float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
+                        v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
+                        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+                        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
+                        xh[p] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
+                        xl[p] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
                     }
-                    const int hh = H >> 1, hw = W >> 1;
-                    float* prow = g.pool_out + (((size_t)(j_out >> 2) * hh + (y >> 1)) * hw + (tx0 >> 1)) * 4;
+                    issue(rs);
+                    const unsigned char* wl = smem + c * WB + w_rd;
 #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        float v[4] = {hv[half * 4], hv[half * 4 + 1], hv[half * 4 + 2], hv[half * 4 + 3]};
-                        quad_transpose_dpp(v, lane);
-                        const int mi = half * 4 + (lane & 3);
-                        const int xp = 4 * (mi >> 1) + 2 * lg + (mi & 1);
-                        if (quad_ok && y < H && tx0 + 2 * xp < W)
-                            *reinterpret_cast<f32x4*>(prow + xp * 4) = f32x4{v[0], v[1], v[2], v[3]};
+                    for (int kx = 0; kx < 3; kx++) {
+                        unsigned sh[4], sl[4];
+#pragma unroll
+                        for (int p = 0; p < 4; p++) {
+                            sh[p] = kx == 1 ? xh[p] : kx == 0 ? dpp_wave_shr1(xh[p]) : dpp_wave_shl1(xh[p]);
+                            sl[p] = kx == 1 ? xl[p] : kx == 0 ? dpp_wave_shr1(xl[p]) : dpp_wave_shl1(xl[p]);
+                        }
+                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+                        const f16x8 fxh = __builtin_bit_cast(f16x8, (u4){sh[0], sh[1], sh[2], sh[3]});
+                        const f16x8 fxl = __builtin_bit_cast(f16x8, (u4){sl[0], sl[1], sl[2], sl[3]});
+#pragma unroll
+                        for (int ky = 0; ky < 3; ky++) {
+                            // output row h - ky lives in accumulator (j - ky) mod 3; rows outside the band are skipped (wave-uniform)
+                            if ((unsigned)(h - ky) >= (unsigned)BH) continue;
+                            f32x16& A = acc[(j - ky + 3) % 3];
+                            const f16x8 fwh = *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
+                            A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, A, 0, 0, 0);
+                            if (!W16) {
+                                const f16x8 fwl = *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
+                                A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, A, 0, 0, 0);
+                            }
+                            A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, A, 0, 0, 0);
+                        }
+                    }
+                }
+                // ---- output row h - 2 is complete (accumulator (j + 1) mod 3).  D (32 x 32): register k of lane l = channel
+                // (k & 3) + 8 (k >> 2) + 4 (l >> 5) of pixel l & 31: registers 4 q .. 4 q + 3 are channel quad 2 q + (l >> 5)
+                const int y = y0 + h - 2;
+                if (h >= 2 && y < H) {
+                    f32x16 t = acc[(j + 1) % 3] * (1.0f / (XS1 * WS1));
+                    if (g.out_lrelu) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int quad = (n0 >> 2) + 2 * q + gq;
+                        if (lane_ok && quad * 4 < g.cout)
+                            *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+                    }
+                    if (POOL) {
+                        // 2x2 pool of the raw output: the row above is in `prev`; columns x (even: odd m) and x + 1 are this lane and the next
+                        if (!(y & 1)) {
+#pragma unroll
+                            for (int k = 0; k < 16; k++) prev[k] = t[k];
+                        } else {
+                            float pv[16];
+#pragma unroll
+                            for (int k = 0; k < 16; k++) {
+                                const bool pos = (posmask >> k) & 1u;
+                                const float v = pos ? fmaxf(prev[k], t[k]) : fminf(prev[k], t[k]);
+                                const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
+                                pv[k] = pos ? fmaxf(v, o) : fminf(v, o);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int quad = (n0 >> 2) + 2 * q + gq;
+                                if ((m & 1) && m < RR_PX && x < W && quad * 4 < g.cout)
+                                    *reinterpret_cast<f32x4*>(g.pool_out + (((size_t)quad * hh + (y >> 1)) * hw + (x >> 1)) * 4) =
+                                        f32x4{pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]};
+                            }
+                        }
+                    }
+                    if (g.stat) {
+                        // BN partial sums of the row: two stages of the halving butterfly (16 -> 4 values per lane), accumulated over the strip
+                        float a8[8], c8[8];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) {
+                            const float lo = lane_ok ? t[k] : 0.0f, hi = lane_ok ? t[8 + k] : 0.0f;
+                            a8[k] = (o1 ? hi : lo) + dpp_xor1(o1 ? lo : hi);
+                            const float lo2 = lo * lo, hi2 = hi * hi;
+                            c8[k] = (o1 ? hi2 : lo2) + dpp_xor1(o1 ? lo2 : hi2);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            s1q[k] += (o2 ? a8[4 + k] : a8[k]) + dpp_xor2(o2 ? a8[k] : a8[4 + k]);
+                            s2q[k] += (o2 ? c8[4 + k] : c8[k]) + dpp_xor2(o2 ? c8[k] : c8[4 + k]);
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { acc0[k] = bj; acc1[k] = 0.f; }
         }
-        m_item = st_item; m_chunk = st_chunk;                  // the cursors move on one step
-        if (++st_chunk == nch) { st_chunk = 0; st_item++; }
-        __syncthreads();
+        if (g.stat) {
+            // the remaining stages: lanes m and m ^ 4, m ^ 8, m ^ 16
+            const bool o4 = m & 4, o8 = m & 8;
+            float e1[2], e2[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                e1[k] = (o4 ? s1q[2 + k] : s1q[k]) + __shfl_xor(o4 ? s1q[k] : s1q[2 + k], 4);
+                e2[k] = (o4 ? s2q[2 + k] : s2q[k]) + __shfl_xor(o4 ? s2q[k] : s2q[2 + k], 4);
+            }
+            float f1 = (o8 ? e1[1] : e1[0]) + __shfl_xor(o8 ? e1[0] : e1[1], 8);
+            float f2 = (o8 ? e2[1] : e2[0]) + __shfl_xor(o8 ? e2[0] : e2[1], 8);
+            f1 += __shfl_xor(f1, 16); f2 += __shfl_xor(f2, 16);
+            fix1 += bn_fix((double)f1); fix2 += bn_fix((double)f2);
+        }
     }
-    // ---- BN sums of this workgroup: lanes li of both halves and all waves hold fixed-point partials of channel n0 + li
+
     if (g.stat) {
-        long long* red = reinterpret_cast<long long*>(smem);   // [8 waves][32][2]; the loop's last barrier has passed
-        fix1 += __shfl_xor(fix1, 32); fix2 += __shfl_xor(fix2, 32);
-        if (lg == 0) { red[(wave * 32 + li) * 2] = fix1; red[(wave * 32 + li) * 2 + 1] = fix2; }
+        if (m < 16) {
+            const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
+            const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)fix1);
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)fix2);
+        }
         __syncthreads();
         if (tid < 32 && n0 + tid < g.cout) {
-            long long a = 0, c = 0;
-            for (int w = 0; w < 8; w++) { a += red[(w * 32 + tid) * 2]; c += red[(w * 32 + tid) * 2 + 1]; }
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * 2);
-            atomicAdd(dst, (unsigned long long)a);
-            atomicAdd(dst + 1, (unsigned long long)c);
+            atomicAdd(dst, (unsigned long long)bnacc[tid * 2]);
+            atomicAdd(dst + 1, (unsigned long long)bnacc[tid * 2 + 1]);
         }
     }
 }
@@ -1455,6 +1757,7 @@ struct LayerW {
     // K16-aligned concat space (source a in chunks [0, ca16), source b after it)
     int coutp32 = 0, nchunks16 = 0, ca16 = 0;
     unsigned char* d_wsplit = nullptr;
+    unsigned char* d_wsplit1 = nullptr;      // the same tiling in the single-accumulator scaling of conv3x3_f16x3r: hi = fp16(2^7 w), lo unscaled
     float* d_bias32 = nullptr;
     unsigned char* d_wsplit_d2s = nullptr;   // the same layout for the depth-to-space form of dec1.c1 (12 virtual outputs in one group)
     float* d_bias32_d2s = nullptr;
@@ -1548,7 +1851,7 @@ static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w_raw16); hipFree(l.d_wsplit_d2s16);
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
-        hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_bias32);
+        hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_wsplit1); hipFree(l.d_bias32);
         hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s); hipFree(l.d_wsplit_d2s); hipFree(l.d_bias32_d2s);
         l = LayerW();
     }
@@ -1593,9 +1896,11 @@ static DenoiseState* state(aipt_ctx* ctx) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->dn->num_cus = prop.multiProcessorCount;
-        // conv3x3_f16x3p declares its LDS at launch: two 40 KB stages + the BN table
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3p<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 82 * 1024);
+        // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return ctx->dn;
 }
@@ -1647,6 +1952,49 @@ static bool conv_fuses_pool(const DenoiseState* s, int H, int W) {
     return on && impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels() && ((long)H * W < f16_min_pixels() || one_row);
 }
 
+// conv3x3_f16x3s: picks the band height (the strips of a level should fill the twelve waves per CU once: cost = rounds x halo
+// rows of a strip) and the instantiation for the layer's chunk count; false when there is none (the caller falls back)
+constexpr int RS_WAVES = 12;
+template <bool W16, int NCH, bool POOL>
+static void launch_strips_t(hipStream_t st, const ConvArgsH& gh, unsigned pgrid, size_t lds) {
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3s<W16, NCH, RS_WAVES, 3, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv3x3_f16x3s<W16, NCH, RS_WAVES, 3, POOL>), dim3(pgrid), dim3(RS_WAVES * 64), lds, st, gh);
+}
+static bool launch_strips(DenoiseState* s, ConvArgsH& gh, int li, bool w16, unsigned pgrid, int wpg, size_t lds) {
+    const bool pool = gh.pool_out != nullptr;
+    const int nch = gh.nchunks;
+    const bool have = nch == 2 || nch == 3 || nch == 4 || (!pool && (nch == 6 || (nch == 8 && !w16)));
+    if (!have) return false;
+    static const int band_env = getenv("AIPT_F16S_BAND") ? atoi(getenv("AIPT_F16S_BAND")) : 0;
+    int best = 0; long best_cost = 0;
+    for (int bh = 4; bh <= 64; bh += 3) {
+        if (pool && (bh & 1)) continue;
+        const int nb = (gh.H + bh - 1) / bh, per = (nb + 7) / 8;
+        const long units = (long)per * gh.tiles_x, waves = (long)wpg * RS_WAVES;
+        const long cost = ((units + waves - 1) / waves) * (bh + 2);
+        if (!best || cost < best_cost) { best = bh; best_cost = cost; }
+    }
+    if (band_env >= 4 && (band_env + 2) % 3 == 0 && !(pool && (band_env & 1))) best = band_env;
+    gh.band = best;
+    gh.tiles_y = (gh.H + best - 1) / best;
+    snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3s<%s,%d>", w16 ? "true" : "false", nch);
+#define AIPT_STRIPS(N) do { if (w16) { if (pool) launch_strips_t<true, N, true>(s->cur, gh, pgrid, lds); else launch_strips_t<true, N, false>(s->cur, gh, pgrid, lds); } \
+                            else { if (pool) launch_strips_t<false, N, true>(s->cur, gh, pgrid, lds); else launch_strips_t<false, N, false>(s->cur, gh, pgrid, lds); } } while (0)
+    switch (nch) {
+        case 2: AIPT_STRIPS(2); break;
+        case 3: AIPT_STRIPS(3); break;
+        case 4: AIPT_STRIPS(4); break;
+        case 6: if (w16) launch_strips_t<true, 6, false>(s->cur, gh, pgrid, lds); else launch_strips_t<false, 6, false>(s->cur, gh, pgrid, lds); break;
+        default: launch_strips_t<false, 8, false>(s->cur, gh, pgrid, lds); break;
+    }
+#undef AIPT_STRIPS
+    return true;
+}
+
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
                     int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr) {
     const LayerW& L = s->L[li];
@@ -1695,7 +2043,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
-        gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
+        gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0; gh.band = 0;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
@@ -1741,22 +2089,32 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = 0;
         gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
         static const int ablate_env = getenv("AIPT_CONV_ABLATE") ? (int)strtol(getenv("AIPT_CONV_ABLATE"), nullptr, 0) : 0;
-        gh.ablate = ablate_env;
+        gh.ablate = ablate_env; gh.band = 0;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
         f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
-        // the two biggest levels (>= 1024 (tile, group) pairs): persistent, continuously pipelined kernel, two workgroups per CU
-        static const int persist_env = getenv("AIPT_F16_PERSIST") ? atoi(getenv("AIPT_F16_PERSIST")) : 0;
-        const int wg_per_xcd = 2 * s->num_cus / 8;
-        const bool persist = persist_env && rows == 8 && nwv == 8 && !gh.a.planar && (long)grid.x * grid.y * grid.z >= 1024 &&
-                             wg_per_xcd / (int)grid.z >= 1 && 2 * convp_lds_bytes(gh.nchunks) <= 160 * 1024;
-        if (persist) {
-            const unsigned pgrid = 8u * (unsigned)(wg_per_xcd / (int)grid.z) * grid.z;
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3p<%s>", w16 ? "true" : "false");
-            if (w16) hipLaunchKernelGGL((conv3x3_f16x3p<true>), dim3(pgrid), dim3(512), convp_lds_bytes(gh.nchunks), s->cur, gh);
-            else hipLaunchKernelGGL((conv3x3_f16x3p<false>), dim3(pgrid), dim3(512), convp_lds_bytes(gh.nchunks), s->cur, gh);
+        // the big levels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit LDS
+        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 200000;
+        const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
+        if (!gh.a.planar && (long)H * W >= r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 &&
+            !(H & 1) && !(W & 1)) {
+            gh.wsplit = L.d_wsplit1;
+            gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + RR_ROWS - 1) / RR_ROWS; gh.groups = r_groups;
+            const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
+            const size_t lds = convr_lds_bytes(gh.nchunks, w16);
+            static const int s_env = getenv("AIPT_F16S") ? atoi(getenv("AIPT_F16S")) : 1;
+            if (s_env && launch_strips(s, gh, li, w16, pgrid, r_wpg, lds)) {
+            } else
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s>", w16 ? "true" : "false");
+            static const int r_var = getenv("AIPT_F16R_VARIANT") ? atoi(getenv("AIPT_F16R_VARIANT")) : 0;
+            {
+            if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            else if (r_var == 3) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 6, false>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            else if (r_var == 2) hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            }
         } else if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
             if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
@@ -1924,7 +2282,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             L.ca16 = pad16(L.ca) / KH;
             L.nchunks16 = L.ca16 + pad16(cb) / KH;
             const size_t nh = (size_t)(L.coutp32 / 32) * L.nchunks16 * (WSLAB / 2);
-            std::vector<_Float16> ws(nh, (_Float16)0.0f);
+            std::vector<_Float16> ws(nh, (_Float16)0.0f), ws1(nh, (_Float16)0.0f);
             for (int j = 0; j < L.cout; j++)
                 for (int c = 0; c < L.cin; c++) {
                     const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
@@ -1935,8 +2293,14 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                         const size_t o = slab + ((size_t)t * 32 + (j % 32)) * KH + (kc % KH);
                         ws[o] = h;
                         ws[o + 9 * 32 * KH] = (_Float16)((v - (float)h) * LO_SCALE);
+                        const float v1 = w[((size_t)j * L.cin + c) * 9 + t] * WS1;
+                        const _Float16 h1 = (_Float16)v1;
+                        ws1[o] = h1;
+                        ws1[o + 9 * 32 * KH] = (_Float16)(v1 - (float)h1);
                     }
                 }
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit1, nh * 2));
+            AIPT_HIP(ctx, hipMemcpy(L.d_wsplit1, ws1.data(), nh * 2, hipMemcpyHostToDevice));
             std::vector<float> b32(L.coutp32, 0.0f);
             memcpy(b32.data(), b, 4 * L.cout);
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit, nh * 2));

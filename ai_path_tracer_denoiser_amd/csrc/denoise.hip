@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace aipt {
 
@@ -481,7 +482,7 @@ struct ConvArgsH {
     // bit for bit, as pooling the normalised tensor, without a pass over it (pool2_norm: 5 launches, 57 us per frame)
     float* pool_out;               // [ceil(cout/4)][H/2][W/2][4] or nullptr
     const float* pool_gamma;       // [cout]
-    int band;                      // conv3x3_f16x3s: output rows of a strip (band + 2 is a multiple of 3)
+    int band;                      // conv3x3_f16x3s: output rows of a strip (band - 2 is a multiple of 3)
     int ablate;                    // -DAIPT_CONV_ABLATE builds only (tools/conv_ablate.sh): bit mask of the parts to leave out
 };
 
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WB = W16 ? WSLAB / 2 : WSLAB;                // LDS bytes of a chunk's weights
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, gq = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 31, gq = lane >> 5;   // (wave: an SGPR, so is everything derived from it)
     const int nch = g.nchunks, ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up;
     float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
     constexpr int NT = NWV * 64;
     constexpr int WB = W16 ? WSLAB / 2 : WSLAB;
     static_assert((3 * NCH) % PF == 0, "the ring slot of a step must be static");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, gq = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 31, gq = lane >> 5;   // (wave: an SGPR, so is everything derived from it)
     const int ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up, BH = g.band;
     float* tab_a = reinterpret_cast<float*>(smem + NCH * WB);
     float* tab_b = tab_a + NCH * KH;
@@ -1263,8 +1264,9 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
     long long fix1 = 0, fix2 = 0;
     const bool o1 = m & 1, o2 = m & 2;
 
-    // ---- prefetch cursor (unit, halo row, chunk), PF steps ahead of the consumer
-    int pf_u = u, pf_h = 0, pf_c = 0, pf_y0 = 0;
+    // ---- prefetch cursor (halo row, chunk) of the wave's strip, PF steps ahead of the consumer (a strip is long: the ring is
+    // primed again at the start of each)
+    int pf_h = 0, pf_c = 0, pf_y0 = 0;
     unsigned pf_xo = 0;
     auto pf_unit = [&](int unit) {
         const int bd = unit / tiles_x, tx = unit - bd * tiles_x;
@@ -1273,6 +1275,10 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
         pf_xo = (unsigned)(up ? (x >> 1) : x) * 16u;
     };
     f32x4 raw[PF][2];
+#ifdef AIPT_CONV_ABLATE
+#pragma unroll
+    for (int s_ = 0; s_ < PF; s_++) { raw[s_][0] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; raw[s_][1] = raw[s_][0]; }
+#endif
     auto issue = [&](int rs) {                                 // the cursor's step into ring slot rs, then advance the cursor
         const int y = min(max(pf_y0 - 1 + pf_h, 0), H - 1);
         const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
@@ -1283,21 +1289,15 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
         const int nq = (pad4(sr.C) >> 2) - cl * 4;
         const unsigned q0 = 2 * gq < nq ? (unsigned)(2 * gq) * plane16 : 0u;
         const unsigned q1 = 2 * gq + 1 < nq ? (unsigned)(2 * gq + 1) * plane16 : 0u;
+#ifdef AIPT_CONV_ABLATE
+        if (g.ablate & 2) { raw[rs][0] += 1.0f; raw[rs][1] += 1.0f; } else
+#endif
+        {
         raw[rs][0] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q0));
         raw[rs][1] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q1));
-        if (++pf_c == NCH) {
-            pf_c = 0;
-            if (++pf_h == BH + 2) {
-                pf_h = 0;
-                if (pf_u + stride < nunits) { pf_u += stride; pf_unit(pf_u); }     // (past the end: harmless re-reads)
-            }
         }
+        if (++pf_c == NCH) { pf_c = 0; pf_h = min(pf_h + 1, BH + 1); }           // (past the strip's end: harmless re-reads)
     };
-    if (u < nunits) {
-        pf_unit(u);
-#pragma unroll
-        for (int s = 0; s < PF; s++) issue(s);
-    }
 
     const int hh = H >> 1, hw = W >> 1;
     for (; u < nunits; u += stride) {
@@ -1308,10 +1308,16 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
         float s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};     // BN partials of the strip, two butterfly stages in
         f32x16 acc[3];
         float prev[POOL ? 16 : 1];
-        for (int h0 = 0; h0 < BH + 2; h0 += 3) {
+        pf_unit(u); pf_h = 0; pf_c = 0;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int h = h0 + j;
+        for (int s = 0; s < PF; s++) issue(s);
+        // One halo row: J = h mod 3 (its accumulator), SB = ring slot of its first step, V0..V2: which tap rows have an output row
+        // inside the band (static: rows 0, 1 and BH, BH+1 are peeled off the row loop), EPI: output row h - 2 is complete after it.
+        auto halo_row = [&](auto jt, auto sbt, auto v0t, auto v1t, auto v2t, auto epit, const int h) __attribute__((always_inline)) {
+            constexpr int j = decltype(jt)::value, SB = decltype(sbt)::value;
+            constexpr bool V[3] = {decltype(v0t)::value, decltype(v1t)::value, decltype(v2t)::value};
+            constexpr bool EPI = decltype(epit)::value;
+            {
                 // accumulator j starts output row h from the bias
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -1323,7 +1329,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
 #pragma unroll
                 for (int c = 0; c < NCH; c++) {
                     __builtin_amdgcn_sched_barrier(0);
-                    const int rs = (j * NCH + c) % PF;
+                    const int rs = (SB + c) % PF;
                     const float slope = c < ca16 ? g.a.slope : g.b.slope;
                     const float* ta = tab_a + c * KH + gq * 8;
                     const float* tb = tab_b + c * KH + gq * 8;
@@ -1345,6 +1351,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
                     }
                     issue(rs);
                     const unsigned char* wl = smem + c * WB + w_rd;
+                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++) {
                         unsigned sh[4], sl[4];
@@ -1353,14 +1360,15 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
                             sh[p] = kx == 1 ? xh[p] : kx == 0 ? dpp_wave_shr1(xh[p]) : dpp_wave_shl1(xh[p]);
                             sl[p] = kx == 1 ? xl[p] : kx == 0 ? dpp_wave_shr1(xl[p]) : dpp_wave_shl1(xl[p]);
                         }
-                        typedef unsigned u4 __attribute__((ext_vector_type(4)));
                         const f16x8 fxh = __builtin_bit_cast(f16x8, (u4){sh[0], sh[1], sh[2], sh[3]});
                         const f16x8 fxl = __builtin_bit_cast(f16x8, (u4){sl[0], sl[1], sl[2], sl[3]});
 #pragma unroll
                         for (int ky = 0; ky < 3; ky++) {
-                            // output row h - ky lives in accumulator (j - ky) mod 3; rows outside the band are skipped (wave-uniform)
-                            if ((unsigned)(h - ky) >= (unsigned)BH) continue;
-                            f32x16& A = acc[(j - ky + 3) % 3];
+                            if (!V[ky]) continue;                                  // static
+#ifdef AIPT_CONV_ABLATE
+                            if (g.ablate & 1) continue;
+#endif
+                            f32x16& A = acc[(j - ky + 3) % 3];                     // output row h - ky
                             const f16x8 fwh = *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
                             A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, A, 0, 0, 0);
                             if (!W16) {
@@ -1374,7 +1382,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
                 // ---- output row h - 2 is complete (accumulator (j + 1) mod 3).  D (32 x 32): register k of lane l = channel
                 // (k & 3) + 8 (k >> 2) + 4 (l >> 5) of pixel l & 31: registers 4 q .. 4 q + 3 are channel quad 2 q + (l >> 5)
                 const int y = y0 + h - 2;
-                if (h >= 2 && y < H) {
+                if (EPI && y < H) {
                     f32x16 t = acc[(j + 1) % 3] * (1.0f / (XS1 * WS1));
                     if (g.out_lrelu) {
 #pragma unroll
@@ -1383,6 +1391,9 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int quad = (n0 >> 2) + 2 * q + gq;
+#ifdef AIPT_CONV_ABLATE
+                        if (g.ablate & 16) continue;
+#endif
                         if (lane_ok && quad * 4 < g.cout)
                             *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
                     }
@@ -1427,7 +1438,19 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
                     }
                 }
             }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using T = std::true_type; using F = std::false_type;
+        constexpr int SL = (2 * NCH + ((3 * NCH) / PF) * 0) % PF;  // (a trip of three rows advances the ring by a multiple of PF: the slots of the loop are static)
+        halo_row(I0{}, std::integral_constant<int, 0>{}, T{}, F{}, F{}, F{}, 0);
+        halo_row(I1{}, std::integral_constant<int, NCH % PF>{}, T{}, T{}, F{}, F{}, 1);
+        for (int h = 2; h < BH; h += 3) {                      // BH - 2 is a multiple of 3
+            halo_row(I2{}, std::integral_constant<int, SL>{}, T{}, T{}, T{}, T{}, h);
+            halo_row(I0{}, std::integral_constant<int, (SL + NCH) % PF>{}, T{}, T{}, T{}, T{}, h + 1);
+            halo_row(I1{}, std::integral_constant<int, (SL + 2 * NCH) % PF>{}, T{}, T{}, T{}, T{}, h + 2);
         }
+        halo_row(I2{}, std::integral_constant<int, SL>{}, F{}, T{}, T{}, T{}, BH);
+        halo_row(I0{}, std::integral_constant<int, (SL + NCH) % PF>{}, F{}, F{}, T{}, T{}, BH + 1);
         if (g.stat) {
             // the remaining stages: lanes m and m ^ 4, m ^ 8, m ^ 16
             const bool o4 = m & 4, o8 = m & 8;
@@ -1971,14 +1994,14 @@ static bool launch_strips(DenoiseState* s, ConvArgsH& gh, int li, bool w16, unsi
     if (!have) return false;
     static const int band_env = getenv("AIPT_F16S_BAND") ? atoi(getenv("AIPT_F16S_BAND")) : 0;
     int best = 0; long best_cost = 0;
-    for (int bh = 4; bh <= 64; bh += 3) {
+    for (int bh = 5; bh <= 65; bh += 3) {
         if (pool && (bh & 1)) continue;
         const int nb = (gh.H + bh - 1) / bh, per = (nb + 7) / 8;
         const long units = (long)per * gh.tiles_x, waves = (long)wpg * RS_WAVES;
         const long cost = ((units + waves - 1) / waves) * (bh + 2);
         if (!best || cost < best_cost) { best = bh; best_cost = cost; }
     }
-    if (band_env >= 4 && (band_env + 2) % 3 == 0 && !(pool && (band_env & 1))) best = band_env;
+    if (band_env >= 5 && (band_env - 2) % 3 == 0 && !(pool && (band_env & 1))) best = band_env;
     gh.band = best;
     gh.tiles_y = (gh.H + best - 1) / best;
     snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3s<%s,%d>", w16 ? "true" : "false", nch);
@@ -2104,7 +2127,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + RR_ROWS - 1) / RR_ROWS; gh.groups = r_groups;
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
-            static const int s_env = getenv("AIPT_F16S") ? atoi(getenv("AIPT_F16S")) : 1;
+            static const int s_env = getenv("AIPT_F16S") ? atoi(getenv("AIPT_F16S")) : 0;
             if (s_env && launch_strips(s, gh, li, w16, pgrid, r_wpg, lds)) {
             } else
             snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s>", w16 ? "true" : "false");

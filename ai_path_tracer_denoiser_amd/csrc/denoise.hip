@@ -482,7 +482,6 @@ struct ConvArgsH {
     // bit for bit, as pooling the normalised tensor, without a pass over it (pool2_norm: 5 launches, 57 us per frame)
     float* pool_out;               // [ceil(cout/4)][H/2][W/2][4] or nullptr
     const float* pool_gamma;       // [cout]
-    int band;                      // conv3x3_f16x3s: output rows of a strip (band - 2 is a multiple of 3)
     int ablate;                    // -DAIPT_CONV_ABLATE builds only (tools/conv_ablate.sh): bit mask of the parts to leave out
 };
 
@@ -908,9 +907,17 @@ constexpr int RR_ROWS = 4, RR_PX = 30;
 constexpr float XS1 = 16.0f, WS1 = 128.0f;
 constexpr int RR_MAXCH = 8;                                   // chunks whose weights fit LDS (fp16-weight mode: twice as many)
 static inline size_t convr_lds_bytes(int nchunks, bool w16) {
-    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * 2 * 8;
+    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * 2 * 8 + 32;
 }
 
+// lo half of the split: the fp16 roundings of v0 - hi.lo and v1 - hi.hi, packed, in two mixed-precision FMAs (instead of two
+// conversions, two subtractions and a pack: VALU instructions add to the MFMA time of a SIMD, tools/ubench/valu_mfma.hip)
+__device__ __forceinline__ unsigned split_lo_mix(unsigned hi, float v0, float v1) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(v1));
+    return d;
+}
 __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned v) {   // lane i <- lane i - 1
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
 }
@@ -945,6 +952,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     float* tab_b = tab_a + nch * KH;
     float* bias_s = tab_b + nch * KH;                          // [32], times 2^11: the accumulators start from it
     long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][2]
+    const float* zeros = reinterpret_cast<const float*>(bnacc + 64);  // [8]: the BN coefficients of out-of-image pixels
 
     // ---- workgroup -> (XCD, output-channel group); XCD b & 7 owns a contiguous band of item rows
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
@@ -952,6 +960,53 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     const int gz = slot % groups, wi = slot / groups;
     if (wi >= wpg) return;
     const int n0 = gz * 32;
+
+    const int tiles_x = g.tiles_x;
+    const int per = (g.tiles_y + 7) >> 3, rb0 = xcd * per, rb1 = min(g.tiles_y, rb0 + per);
+    const int nitems = max(0, rb1 - rb0) * tiles_x, stride = wpg * RR_WAVES;
+    int it = wave * wpg + wi;                                  // consecutive items go to different workgroups: even load per CU
+    const int sw = up ? (W >> 1) : W;
+    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;
+    const int w_rd = m * 32 + (((gq ^ (m >> 3)) & 1) << 4);
+    // pool: bit k set = register k's channel pools with max (gamma >= 0), else min
+    unsigned posmask = 0xFFFFu;
+    if (g.pool_out) {
+        posmask = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int c = n0 + (k & 3) + 8 * (k >> 2) + 4 * gq;
+            posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
+        }
+    }
+    float bsum1 = 0.f, bsum2 = 0.f;                            // BN sums of this lane's channel over all items of the wave (a fixed order)
+
+    // ---- prefetch cursor: (item, chunk, halo row) PF rows ahead of the consumer; the first rows are requested before the prologue
+    int pf_it = it, pf_c = 0, pf_y0 = 0;
+    unsigned pf_v0 = 0, pf_v1 = 0;                             // this lane's byte offsets inside a chunk's row: pixel + its two channel quads
+    auto pf_item = [&](int item) {                             // geometry of the cursor's item
+        const int rb = item / tiles_x, tx = item - rb * tiles_x;
+        pf_y0 = (rb0 + rb) * RR_ROWS;
+        const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
+        pf_v0 = (unsigned)(up ? (x >> 1) : x) * 16u + (unsigned)(2 * gq) * plane16;
+        pf_v1 = pf_v0 + plane16;
+    };
+    f32x4 raw[PF][2];
+    auto issue = [&](int slot, int hp) {                       // the two channel quads of this lane's pixel in halo row hp
+        const int y = min(max(pf_y0 - 1 + hp, 0), H - 1);
+        const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
+        const bool fa = pf_c < ca16;
+        const int cl = fa ? pf_c : pf_c - ca16;
+        const ConvSrc& sr = fa ? g.a : g.b;
+        // (tensors are allocated in whole 16-channel chunks: no clamping of pad quads; scalar row base + per-lane offset)
+        const unsigned char* rowp = reinterpret_cast<const unsigned char*>(sr.p) + ((size_t)cl * 4 * plane16 + roff);
+        raw[slot][0] = *reinterpret_cast<const f32x4*>(rowp + pf_v0);
+        raw[slot][1] = *reinterpret_cast<const f32x4*>(rowp + pf_v1);
+    };
+    if (it < nitems) {
+        pf_item(it);
+#pragma unroll
+        for (int h = 0; h < PF; h++) issue(h, h);
+    }
 
     // ---- prologue: weights of all chunks, BN coefficient table, bias -> LDS
     {
@@ -973,56 +1028,9 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         }
         if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (XS1 * WS1);
         if (tid < 64) bnacc[tid] = 0;
+        if (tid < 8) const_cast<float*>(zeros)[tid] = 0.0f;
     }
     __syncthreads();
-
-    const int tiles_x = g.tiles_x;
-    const int per = (g.tiles_y + 7) >> 3, rb0 = xcd * per, rb1 = min(g.tiles_y, rb0 + per);
-    const int nitems = max(0, rb1 - rb0) * tiles_x, stride = wpg * RR_WAVES;
-    int it = wave * wpg + wi;                                  // consecutive items go to different workgroups: even load per CU
-    const int sw = up ? (W >> 1) : W;
-    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;
-    const int w_rd = m * 32 + (((gq ^ (m >> 3)) & 1) << 4);
-    // pool: bit k set = register k's channel pools with max (gamma >= 0), else min
-    unsigned posmask = 0xFFFFu;
-    if (g.pool_out) {
-        posmask = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int c = n0 + (k & 3) + 8 * (k >> 2) + 4 * gq;
-            posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
-        }
-    }
-    long long fix1 = 0, fix2 = 0;                              // BN sums of this lane's channel over all items of the wave
-
-    // ---- prefetch cursor: (item, chunk, halo row) three rows ahead of the consumer
-    int pf_it = it, pf_c = 0, pf_y0 = 0;
-    unsigned pf_xo = 0;
-    auto pf_item = [&](int item) {                             // geometry of the cursor's item
-        const int rb = item / tiles_x, tx = item - rb * tiles_x;
-        pf_y0 = (rb0 + rb) * RR_ROWS;
-        const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
-        pf_xo = (unsigned)(up ? (x >> 1) : x) * 16u;
-    };
-    f32x4 raw[PF][2];
-    auto issue = [&](int slot, int hp) {                       // the two channel quads of this lane's pixel in halo row hp
-        const int y = min(max(pf_y0 - 1 + hp, 0), H - 1);
-        const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
-        const bool fa = pf_c < ca16;
-        const int cl = fa ? pf_c : pf_c - ca16;
-        const ConvSrc& sr = fa ? g.a : g.b;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(sr.p) + (size_t)cl * 4 * plane16;
-        const int nq = (pad4(sr.C) >> 2) - cl * 4;             // real quads of this chunk (pad quads re-read quad 0: their a, b are 0)
-        const unsigned q0 = 2 * gq < nq ? (unsigned)(2 * gq) * plane16 : 0u;
-        const unsigned q1 = 2 * gq + 1 < nq ? (unsigned)(2 * gq + 1) * plane16 : 0u;
-        raw[slot][0] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q0));
-        raw[slot][1] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q1));
-    };
-    if (it < nitems) {
-        pf_item(it);
-#pragma unroll
-        for (int h = 0; h < PF; h++) issue(h, h);
-    }
 
     const int hh = H >> 1, hw = W >> 1;
     for (; it < nitems; it += stride) {
@@ -1062,11 +1070,14 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
                 // ---- transform + split this lane's 8 channels of halo row h.  (Nothing of this row may be scheduled above this
                 // point: hipcc otherwise hoists the rows' first FMAs -- and with them the wait for loads issued one row ago.)
                 __builtin_amdgcn_sched_barrier(0);
+                // zero padding in the normalised domain: an out-of-image pixel takes its coefficients from the zero block (WC: masked below)
+                const bool ok = xin && (unsigned)(y0 - 1 + h) < (unsigned)H;
                 if (!WC) {
-                    a0 = *reinterpret_cast<const f32x4*>(ta); a1 = *reinterpret_cast<const f32x4*>(ta + 4);
-                    b0 = *reinterpret_cast<const f32x4*>(tb); b1 = *reinterpret_cast<const f32x4*>(tb + 4);
+                    const float* tal = ok ? ta : zeros;
+                    const float* tbl = ok ? tb : zeros;
+                    a0 = *reinterpret_cast<const f32x4*>(tal); a1 = *reinterpret_cast<const f32x4*>(tal + 4);
+                    b0 = *reinterpret_cast<const f32x4*>(tbl); b1 = *reinterpret_cast<const f32x4*>(tbl + 4);
                 }
-                const bool ok = xin && (unsigned)(y0 - 1 + h) < (unsigned)H;      // zero padding in the normalised domain
                 unsigned xh[4], xl[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
@@ -1076,10 +1087,9 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
                     const int e = (p & 1) * 2;
                     float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
                     v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
-                    const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-                    const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(fmaf((float)hi[0], -1.0f, v0), fmaf((float)hi[1], -1.0f, v1)));
-                    xh[p] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
-                    xl[p] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
+                    xh[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+                    xl[p] = split_lo_mix(xh[p], v0, v1);
+                    if (WC) { xh[p] = ok ? xh[p] : 0u; xl[p] = ok ? xl[p] : 0u; }
                 }
                 // ---- the ring slot is free: fetch PF rows ahead (into the next chunk / the next item when that wraps)
                 if ((h + PF) % (RR_ROWS + 2) == 0) {
@@ -1171,8 +1181,8 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         if (g.stat) {
 #pragma unroll
             for (int k = 0; k < 16; k++) { s1[k] = lane_ok ? s1[k] : 0.f; s2[k] = lane_ok ? s2[k] : 0.f; }
-            fix1 += bn_fix((double)halfwave_sum16(s1, m));
-            fix2 += bn_fix((double)halfwave_sum16(s2, m));
+            bsum1 += halfwave_sum16(s1, m);
+            bsum2 += halfwave_sum16(s2, m);
         }
     }
 
@@ -1181,298 +1191,8 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         if (m < 16) {
             const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
             const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)fix1);
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)fix2);
-        }
-        __syncthreads();
-        if (tid < 32 && n0 + tid < g.cout) {
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * 2);
-            atomicAdd(dst, (unsigned long long)bnacc[tid * 2]);
-            atomicAdd(dst + 1, (unsigned long long)bnacc[tid * 2 + 1]);
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------- split-fp16 conv, sliding strips
-// conv3x3_f16x3s: conv3x3_f16x3r with the loop nest turned inside out.  A wave owns a STRIP: 30 output columns x a band of BH rows
-// (x 32 output channels), and slides down it: for each halo row, for each 16-channel chunk: load (a register ring, PF steps ahead),
-// transform, split, shift, and 27 MFMAs into the THREE live accumulators (output rows h, h-1, h-2 = tap rows 0, 1, 2).  When a
-// halo row is done, output row h-2 is complete: epilogue of one row (scale, LeakyReLU, C4 stores, pool, BN partial sums), and its
-// accumulator starts the row h+1.  Against the 4-row items of conv3x3_f16x3r:
-//   * every halo row of the strip is loaded and transformed ONCE ((BH+2)/BH instead of 6/4 of the input through L1 and the VALU);
-//   * every step is the full 27 MFMAs; 48 accumulator registers instead of 64; no weight-fragment cache: the chunk loop is
-//     unrolled (NCH is a template parameter) and the 18 fragments of a step are read from LDS where they are used (0.67 reads per
-//     MFMA, LDS 40 % busy at twelve waves) -- 168 VGPRs, THREE waves per SIMD, twelve independent waves per CU;
-//   * one strip per wave and launch where the level allows it (BH is chosen per level so that the strips fill the waves once).
-// BH + 2 is a multiple of 3 (the accumulator that a halo row starts is static: the row loop is unrolled by three).
-template <bool W16, int NCH, int NWV, int PF, bool POOL>
-__global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3s(const ConvArgsH g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = NWV * 64;
-    constexpr int WB = W16 ? WSLAB / 2 : WSLAB;
-    static_assert((3 * NCH) % PF == 0, "the ring slot of a step must be static");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 31, gq = lane >> 5;   // (wave: an SGPR, so is everything derived from it)
-    const int ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up, BH = g.band;
-    float* tab_a = reinterpret_cast<float*>(smem + NCH * WB);
-    float* tab_b = tab_a + NCH * KH;
-    float* bias_s = tab_b + NCH * KH;
-    long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);
-
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
-    const int wpg = (int)(gridDim.x >> 3) / groups;
-    const int gz = slot % groups, wi = slot / groups;
-    if (wi >= wpg) return;
-    const int n0 = gz * 32;
-    {
-        const unsigned char* src = g.wsplit + (size_t)gz * g.wchunks * WSLAB;
-        constexpr int PPC = WB / 16;
-        for (int p = tid; p < NCH * PPC; p += NT) {
-            const int c = p / PPC, pp = p - c * PPC, row = pp >> 1;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)c * WSLAB + pp * 16);
-            *reinterpret_cast<u32x4*>(smem + c * WB + row * 32 + ((((pp & 1) ^ (row >> 3)) & 1) << 4)) = v;
-        }
-        for (int kc = tid; kc < NCH * KH; kc += NT) {
-            const bool fa = kc < ca16 * KH;
-            const int c = fa ? kc : kc - ca16 * KH;
-            const ConvSrc& sr = fa ? g.a : g.b;
-            float2 t = make_float2(0.0f, 0.0f);
-            if (c < sr.C) t = bn_ab(sr.bn, c);
-            tab_a[kc] = t.x * XS1;
-            tab_b[kc] = t.y * XS1;
-        }
-        if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (XS1 * WS1);
-        if (tid < 64) bnacc[tid] = 0;
-    }
-    __syncthreads();
-
-    const int tiles_x = g.tiles_x;
-    const int per = (g.tiles_y + 7) >> 3, bd0 = xcd * per, bd1 = min(g.tiles_y, bd0 + per);
-    const int nunits = max(0, bd1 - bd0) * tiles_x, stride = wpg * NWV;
-    int u = wave * wpg + wi;
-    const int sw = up ? (W >> 1) : W;
-    const unsigned plane16 = (unsigned)((up ? (H >> 1) : H) * sw) * 16u;
-    const int w_rd = m * 32 + (((gq ^ (m >> 3)) & 1) << 4);
-    unsigned posmask = 0xFFFFu;
-    if (POOL) {
-        posmask = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int c = n0 + (k & 3) + 8 * (k >> 2) + 4 * gq;
-            posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
-        }
-    }
-    long long fix1 = 0, fix2 = 0;
-    const bool o1 = m & 1, o2 = m & 2;
-
-    // ---- prefetch cursor (halo row, chunk) of the wave's strip, PF steps ahead of the consumer (a strip is long: the ring is
-    // primed again at the start of each)
-    int pf_h = 0, pf_c = 0, pf_y0 = 0;
-    unsigned pf_xo = 0;
-    auto pf_unit = [&](int unit) {
-        const int bd = unit / tiles_x, tx = unit - bd * tiles_x;
-        pf_y0 = (bd0 + bd) * BH;
-        const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
-        pf_xo = (unsigned)(up ? (x >> 1) : x) * 16u;
-    };
-    f32x4 raw[PF][2];
-#ifdef AIPT_CONV_ABLATE
-#pragma unroll
-    for (int s_ = 0; s_ < PF; s_++) { raw[s_][0] = f32x4{0.5f, 0.25f, 0.125f, 1.0f}; raw[s_][1] = raw[s_][0]; }
-#endif
-    auto issue = [&](int rs) {                                 // the cursor's step into ring slot rs, then advance the cursor
-        const int y = min(max(pf_y0 - 1 + pf_h, 0), H - 1);
-        const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
-        const bool fa = pf_c < ca16;
-        const int cl = fa ? pf_c : pf_c - ca16;
-        const ConvSrc& sr = fa ? g.a : g.b;
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(sr.p) + (size_t)cl * 4 * plane16;
-        const int nq = (pad4(sr.C) >> 2) - cl * 4;
-        const unsigned q0 = 2 * gq < nq ? (unsigned)(2 * gq) * plane16 : 0u;
-        const unsigned q1 = 2 * gq + 1 < nq ? (unsigned)(2 * gq + 1) * plane16 : 0u;
-#ifdef AIPT_CONV_ABLATE
-        if (g.ablate & 2) { raw[rs][0] += 1.0f; raw[rs][1] += 1.0f; } else
-#endif
-        {
-        raw[rs][0] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q0));
-        raw[rs][1] = *reinterpret_cast<const f32x4*>(base + (roff + pf_xo + q1));
-        }
-        if (++pf_c == NCH) { pf_c = 0; pf_h = min(pf_h + 1, BH + 1); }           // (past the strip's end: harmless re-reads)
-    };
-
-    const int hh = H >> 1, hw = W >> 1;
-    for (; u < nunits; u += stride) {
-        const int bd = u / tiles_x, tx = u - bd * tiles_x;
-        const int y0 = (bd0 + bd) * BH, x = tx * RR_PX - 1 + m;
-        const bool xin = x >= 0 && x < W;
-        const bool lane_ok = m >= 1 && m <= RR_PX && x < W;
-        float s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};     // BN partials of the strip, two butterfly stages in
-        f32x16 acc[3];
-        float prev[POOL ? 16 : 1];
-        pf_unit(u); pf_h = 0; pf_c = 0;
-#pragma unroll
-        for (int s = 0; s < PF; s++) issue(s);
-        // One halo row: J = h mod 3 (its accumulator), SB = ring slot of its first step, V0..V2: which tap rows have an output row
-        // inside the band (static: rows 0, 1 and BH, BH+1 are peeled off the row loop), EPI: output row h - 2 is complete after it.
-        auto halo_row = [&](auto jt, auto sbt, auto v0t, auto v1t, auto v2t, auto epit, const int h) __attribute__((always_inline)) {
-            constexpr int j = decltype(jt)::value, SB = decltype(sbt)::value;
-            constexpr bool V[3] = {decltype(v0t)::value, decltype(v1t)::value, decltype(v2t)::value};
-            constexpr bool EPI = decltype(epit)::value;
-            {
-                // accumulator j starts output row h from the bias
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_s + 8 * q + 4 * gq);
-                    acc[j][4 * q] = bq[0]; acc[j][4 * q + 1] = bq[1]; acc[j][4 * q + 2] = bq[2]; acc[j][4 * q + 3] = bq[3];
-                }
-                const bool rowin = (unsigned)(y0 - 1 + h) < (unsigned)H;
-                const bool ok = xin && rowin;
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int rs = (SB + c) % PF;
-                    const float slope = c < ca16 ? g.a.slope : g.b.slope;
-                    const float* ta = tab_a + c * KH + gq * 8;
-                    const float* tb = tab_b + c * KH + gq * 8;
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ta), a1 = *reinterpret_cast<const f32x4*>(ta + 4);
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(tb), b1 = *reinterpret_cast<const f32x4*>(tb + 4);
-                    unsigned xh[4], xl[4];
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const f32x4& rw = raw[rs][p >> 1];
-                        const f32x4& aa = (p >> 1) ? a1 : a0;
-                        const f32x4& bb = (p >> 1) ? b1 : b0;
-                        const int e = (p & 1) * 2;
-                        float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
-                        v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
-                        const f16x2 hi = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-                        const f16x2 lo = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v0 - (float)hi[0], v1 - (float)hi[1]));
-                        xh[p] = ok ? __builtin_bit_cast(unsigned, hi) : 0u;
-                        xl[p] = ok ? __builtin_bit_cast(unsigned, lo) : 0u;
-                    }
-                    issue(rs);
-                    const unsigned char* wl = smem + c * WB + w_rd;
-                    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-                    for (int kx = 0; kx < 3; kx++) {
-                        unsigned sh[4], sl[4];
-#pragma unroll
-                        for (int p = 0; p < 4; p++) {
-                            sh[p] = kx == 1 ? xh[p] : kx == 0 ? dpp_wave_shr1(xh[p]) : dpp_wave_shl1(xh[p]);
-                            sl[p] = kx == 1 ? xl[p] : kx == 0 ? dpp_wave_shr1(xl[p]) : dpp_wave_shl1(xl[p]);
-                        }
-                        const f16x8 fxh = __builtin_bit_cast(f16x8, (u4){sh[0], sh[1], sh[2], sh[3]});
-                        const f16x8 fxl = __builtin_bit_cast(f16x8, (u4){sl[0], sl[1], sl[2], sl[3]});
-#pragma unroll
-                        for (int ky = 0; ky < 3; ky++) {
-                            if (!V[ky]) continue;                                  // static
-#ifdef AIPT_CONV_ABLATE
-                            if (g.ablate & 1) continue;
-#endif
-                            f32x16& A = acc[(j - ky + 3) % 3];                     // output row h - ky
-                            const f16x8 fwh = *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
-                            A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, A, 0, 0, 0);
-                            if (!W16) {
-                                const f16x8 fwl = *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
-                                A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, A, 0, 0, 0);
-                            }
-                            A = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, A, 0, 0, 0);
-                        }
-                    }
-                }
-                // ---- output row h - 2 is complete (accumulator (j + 1) mod 3).  D (32 x 32): register k of lane l = channel
-                // (k & 3) + 8 (k >> 2) + 4 (l >> 5) of pixel l & 31: registers 4 q .. 4 q + 3 are channel quad 2 q + (l >> 5)
-                const int y = y0 + h - 2;
-                if (EPI && y < H) {
-                    f32x16 t = acc[(j + 1) % 3] * (1.0f / (XS1 * WS1));
-                    if (g.out_lrelu) {
-#pragma unroll
-                        for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const int quad = (n0 >> 2) + 2 * q + gq;
-#ifdef AIPT_CONV_ABLATE
-                        if (g.ablate & 16) continue;
-#endif
-                        if (lane_ok && quad * 4 < g.cout)
-                            *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-                    }
-                    if (POOL) {
-                        // 2x2 pool of the raw output: the row above is in `prev`; columns x (even: odd m) and x + 1 are this lane and the next
-                        if (!(y & 1)) {
-#pragma unroll
-                            for (int k = 0; k < 16; k++) prev[k] = t[k];
-                        } else {
-                            float pv[16];
-#pragma unroll
-                            for (int k = 0; k < 16; k++) {
-                                const bool pos = (posmask >> k) & 1u;
-                                const float v = pos ? fmaxf(prev[k], t[k]) : fminf(prev[k], t[k]);
-                                const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
-                                pv[k] = pos ? fmaxf(v, o) : fminf(v, o);
-                            }
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                const int quad = (n0 >> 2) + 2 * q + gq;
-                                if ((m & 1) && m < RR_PX && x < W && quad * 4 < g.cout)
-                                    *reinterpret_cast<f32x4*>(g.pool_out + (((size_t)quad * hh + (y >> 1)) * hw + (x >> 1)) * 4) =
-                                        f32x4{pv[4 * q], pv[4 * q + 1], pv[4 * q + 2], pv[4 * q + 3]};
-                            }
-                        }
-                    }
-                    if (g.stat) {
-                        // BN partial sums of the row: two stages of the halving butterfly (16 -> 4 values per lane), accumulated over the strip
-                        float a8[8], c8[8];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            const float lo = lane_ok ? t[k] : 0.0f, hi = lane_ok ? t[8 + k] : 0.0f;
-                            a8[k] = (o1 ? hi : lo) + dpp_xor1(o1 ? lo : hi);
-                            const float lo2 = lo * lo, hi2 = hi * hi;
-                            c8[k] = (o1 ? hi2 : lo2) + dpp_xor1(o1 ? lo2 : hi2);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            s1q[k] += (o2 ? a8[4 + k] : a8[k]) + dpp_xor2(o2 ? a8[k] : a8[4 + k]);
-                            s2q[k] += (o2 ? c8[4 + k] : c8[k]) + dpp_xor2(o2 ? c8[k] : c8[4 + k]);
-                        }
-                    }
-                }
-            }
-        };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        using T = std::true_type; using F = std::false_type;
-        constexpr int SL = (2 * NCH + ((3 * NCH) / PF) * 0) % PF;  // (a trip of three rows advances the ring by a multiple of PF: the slots of the loop are static)
-        halo_row(I0{}, std::integral_constant<int, 0>{}, T{}, F{}, F{}, F{}, 0);
-        halo_row(I1{}, std::integral_constant<int, NCH % PF>{}, T{}, T{}, F{}, F{}, 1);
-        for (int h = 2; h < BH; h += 3) {                      // BH - 2 is a multiple of 3
-            halo_row(I2{}, std::integral_constant<int, SL>{}, T{}, T{}, T{}, T{}, h);
-            halo_row(I0{}, std::integral_constant<int, (SL + NCH) % PF>{}, T{}, T{}, T{}, T{}, h + 1);
-            halo_row(I1{}, std::integral_constant<int, (SL + 2 * NCH) % PF>{}, T{}, T{}, T{}, T{}, h + 2);
-        }
-        halo_row(I2{}, std::integral_constant<int, SL>{}, F{}, T{}, T{}, T{}, BH);
-        halo_row(I0{}, std::integral_constant<int, (SL + NCH) % PF>{}, F{}, F{}, T{}, T{}, BH + 1);
-        if (g.stat) {
-            // the remaining stages: lanes m and m ^ 4, m ^ 8, m ^ 16
-            const bool o4 = m & 4, o8 = m & 8;
-            float e1[2], e2[2];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                e1[k] = (o4 ? s1q[2 + k] : s1q[k]) + __shfl_xor(o4 ? s1q[k] : s1q[2 + k], 4);
-                e2[k] = (o4 ? s2q[2 + k] : s2q[k]) + __shfl_xor(o4 ? s2q[k] : s2q[2 + k], 4);
-            }
-            float f1 = (o8 ? e1[1] : e1[0]) + __shfl_xor(o8 ? e1[0] : e1[1], 8);
-            float f2 = (o8 ? e2[1] : e2[0]) + __shfl_xor(o8 ? e2[0] : e2[1], 8);
-            f1 += __shfl_xor(f1, 16); f2 += __shfl_xor(f2, 16);
-            fix1 += bn_fix((double)f1); fix2 += bn_fix((double)f2);
-        }
-    }
-
-    if (g.stat) {
-        if (m < 16) {
-            const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
-            const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)fix1);
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)fix2);
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)bn_fix((double)bsum1));
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)bn_fix((double)bsum2));
         }
         __syncthreads();
         if (tid < 32 && n0 + tid < g.cout) {
@@ -1922,8 +1642,7 @@ static DenoiseState* state(aipt_ctx* ctx) {
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 6, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return ctx->dn;
 }
@@ -1975,49 +1694,6 @@ static bool conv_fuses_pool(const DenoiseState* s, int H, int W) {
     return on && impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels() && ((long)H * W < f16_min_pixels() || one_row);
 }
 
-// conv3x3_f16x3s: picks the band height (the strips of a level should fill the twelve waves per CU once: cost = rounds x halo
-// rows of a strip) and the instantiation for the layer's chunk count; false when there is none (the caller falls back)
-constexpr int RS_WAVES = 12;
-template <bool W16, int NCH, bool POOL>
-static void launch_strips_t(hipStream_t st, const ConvArgsH& gh, unsigned pgrid, size_t lds) {
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3s<W16, NCH, RS_WAVES, 3, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL((conv3x3_f16x3s<W16, NCH, RS_WAVES, 3, POOL>), dim3(pgrid), dim3(RS_WAVES * 64), lds, st, gh);
-}
-static bool launch_strips(DenoiseState* s, ConvArgsH& gh, int li, bool w16, unsigned pgrid, int wpg, size_t lds) {
-    const bool pool = gh.pool_out != nullptr;
-    const int nch = gh.nchunks;
-    const bool have = nch == 2 || nch == 3 || nch == 4 || (!pool && (nch == 6 || (nch == 8 && !w16)));
-    if (!have) return false;
-    static const int band_env = getenv("AIPT_F16S_BAND") ? atoi(getenv("AIPT_F16S_BAND")) : 0;
-    int best = 0; long best_cost = 0;
-    for (int bh = 5; bh <= 65; bh += 3) {
-        if (pool && (bh & 1)) continue;
-        const int nb = (gh.H + bh - 1) / bh, per = (nb + 7) / 8;
-        const long units = (long)per * gh.tiles_x, waves = (long)wpg * RS_WAVES;
-        const long cost = ((units + waves - 1) / waves) * (bh + 2);
-        if (!best || cost < best_cost) { best = bh; best_cost = cost; }
-    }
-    if (band_env >= 5 && (band_env - 2) % 3 == 0 && !(pool && (band_env & 1))) best = band_env;
-    gh.band = best;
-    gh.tiles_y = (gh.H + best - 1) / best;
-    snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3s<%s,%d>", w16 ? "true" : "false", nch);
-#define AIPT_STRIPS(N) do { if (w16) { if (pool) launch_strips_t<true, N, true>(s->cur, gh, pgrid, lds); else launch_strips_t<true, N, false>(s->cur, gh, pgrid, lds); } \
-                            else { if (pool) launch_strips_t<false, N, true>(s->cur, gh, pgrid, lds); else launch_strips_t<false, N, false>(s->cur, gh, pgrid, lds); } } while (0)
-    switch (nch) {
-        case 2: AIPT_STRIPS(2); break;
-        case 3: AIPT_STRIPS(3); break;
-        case 4: AIPT_STRIPS(4); break;
-        case 6: if (w16) launch_strips_t<true, 6, false>(s->cur, gh, pgrid, lds); else launch_strips_t<false, 6, false>(s->cur, gh, pgrid, lds); break;
-        default: launch_strips_t<false, 8, false>(s->cur, gh, pgrid, lds); break;
-    }
-#undef AIPT_STRIPS
-    return true;
-}
-
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
                     int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr) {
     const LayerW& L = s->L[li];
@@ -2066,7 +1742,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
-        gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0; gh.band = 0;
+        gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
         const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
@@ -2112,7 +1788,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = 0;
         gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
         static const int ablate_env = getenv("AIPT_CONV_ABLATE") ? (int)strtol(getenv("AIPT_CONV_ABLATE"), nullptr, 0) : 0;
-        gh.ablate = ablate_env; gh.band = 0;
+        gh.ablate = ablate_env;
         // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
         const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
         f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
@@ -2127,16 +1803,12 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + RR_ROWS - 1) / RR_ROWS; gh.groups = r_groups;
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
-            static const int s_env = getenv("AIPT_F16S") ? atoi(getenv("AIPT_F16S")) : 0;
-            if (s_env && launch_strips(s, gh, li, w16, pgrid, r_wpg, lds)) {
-            } else
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s>", w16 ? "true" : "false");
             static const int r_var = getenv("AIPT_F16R_VARIANT") ? atoi(getenv("AIPT_F16R_VARIANT")) : 0;
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s>", w16 ? "true" : "false", r_var == 1 && !w16 ? "8,3,true" : "12,3,false");
             {
-            if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
-            else if (r_var == 3) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 6, false>), dim3(pgrid), dim3(512), lds, s->cur, gh);
-            else if (r_var == 2) hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            else hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else if (r_var == 1) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
             }
         } else if (gh.a.planar) {
             if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
@@ -2371,10 +2043,12 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     };
     auto mk = [&](Tensor& t, int C, int lvl) -> int {
         t.C = C; t.slope = SLOPE; t.planar = 0;
-        const size_t bytes = sizeof(float) * (size_t)pad4(C) * (height >> lvl) * (width >> lvl);   // C4 layout
+        // C4 layout, allocated up to a multiple of 16 channels: conv3x3_f16x3r fetches whole 16-channel chunks without clamping the
+        // quad index (the extra planes are never written; their BN coefficients are (0, 0))
+        const size_t bytes = sizeof(float) * (size_t)pad16(C) * (height >> lvl) * (width >> lvl);
         int rc = alloc(bytes, (void**)&t.p);
         if (rc) return rc;
-        AIPT_HIP(ctx, hipMemsetAsync(t.p, 0, bytes, ctx->stream));   // pad channels of the last quad stay 0
+        AIPT_HIP(ctx, hipMemsetAsync(t.p, 0, bytes, ctx->stream));   // pad channels and pad planes stay 0
         t.bn = BnRef{nullptr, nullptr, nullptr, nullptr, 0, 0.0};
         return AIPT_OK;
     };

@@ -23,6 +23,8 @@ LIB_PATH = os.environ.get("AIPT_LIB") or os.path.join(_HERE, "libaiptd.so")   # 
 # flags (include/aiptd.h)
 TRACE_AA, TRACE_COMPACT, TRACE_RECORD_MAT0, TRACE_BRUTE_FORCE, TRACE_NO_BROAD_PHASE = 1, 2, 4, 8, 16
 TRACE_SORT_MATERIAL, TRACE_CACHE_FIRST_BOUNCE, TRACE_MOTION_BLUR = 32, 64, 128
+TRACE_NO_CULL, TRACE_DIELECTRIC, TRACE_MESH_NORMAL_VIEW = 512, 1024, 2048
+SCENE_RECOMPUTE_NORMALS = 1
 TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
 DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
 DN_IMPL_MFMA, DN_IMPL_VALU, DN_IMPL_MFMA_F16X3, DN_IMPL_MFMA_F16W = 0, 1, 2, 3
@@ -119,6 +121,7 @@ ABI = [
     ("aipt_comm_destroy", None, [_P]),
     ("aipt_device_count", C.c_int, []),
     ("aipt_scene_load", C.c_int, [C.c_char_p, C.POINTER(_P), C.c_char_p, C.c_size_t]),
+    ("aipt_scene_load_ex", C.c_int, [C.c_char_p, C.c_uint, C.POINTER(_P), C.c_char_p, C.c_size_t]),
     ("aipt_scene_release", None, [_P]),
     ("aipt_scene_set_resolution", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_scene_info", C.c_int, [_P] + [C.POINTER(C.c_int)] * 5),
@@ -189,11 +192,11 @@ def scene_pack(geoms, materials, faces=(), mesh_box=None) -> bytes:
 class Scene:
     """Host-side scene (reference class Scene, scene.h:13-44): parsed by the C++ front end of libaiptd.so."""
 
-    def __init__(self, path: str, res=None, depth=None):
+    def __init__(self, path: str, res=None, depth=None, flags=0):
         L = lib()
         h = _P()
         err = C.create_string_buffer(512)
-        rc = L.aipt_scene_load(path.encode(), C.byref(h), err, 512)
+        rc = L.aipt_scene_load_ex(path.encode(), int(flags), C.byref(h), err, 512)   # flags: SCENE_RECOMPUTE_NORMALS
         if rc:
             raise AiptError(f"aipt_scene_load({path}) failed ({rc}): {err.value.decode()}")
         self._h = h

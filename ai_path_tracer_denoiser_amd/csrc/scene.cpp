@@ -204,7 +204,7 @@ void camera_finish(aipt_scene* s) {                                          // 
 // Minimal Wavefront OBJ reader with tinyobjloader's defaults the reference relies on (triangulate = true,
 // tiny_obj_loader.h:566): v / vn records, faces "f a//c", "f a/b/c", "f a" (1-based, negative = relative), polygons
 // fanned into triangles.  Faces without normals get the geometric normal (the reference would read out of bounds).
-int load_obj(aipt_scene* s, const std::string& path, int materialid, const M4& xf, std::string& err) {
+int load_obj(aipt_scene* s, const std::string& path, int materialid, const M4& xf, unsigned flags, std::string& err) {
     std::ifstream in(path);
     if (!in.is_open()) { err = "cannot open mesh file " + path; return AIPT_E_IO; }
     std::vector<f3> vs, ns;
@@ -257,6 +257,13 @@ int load_obj(aipt_scene* s, const std::string& path, int materialid, const M4& x
                 for (int v = 0; v < 3; v++) {
                     const f3 n = have_n ? normalize3(ns[tri[v].n]) : gn;
                     f.n[v][0] = n.x; f.n[v][1] = n.y; f.n[v][2] = n.z;
+                }
+                if (flags & AIPT_SCENE_RECOMPUTE_NORMALS) {
+                    // RECOMPUTE_NORMALS true (scene.cpp:9, 198-204, 310-311): normalize(cross(p2 - p0, p1 - p0)) goes to n[0] and n[1];
+                    // the reference's statement assigns n[1] twice, so n[2] keeps the zero vector GLM's default constructor gave it
+                    const f3 rn = normalize3(cross3(sub3(p[2], p[0]), sub3(p[1], p[0])));
+                    f.n[0][0] = f.n[1][0] = rn.x; f.n[0][1] = f.n[1][1] = rn.y; f.n[0][2] = f.n[1][2] = rn.z;
+                    f.n[2][0] = f.n[2][1] = f.n[2][2] = 0.0f;
                 }
                 f.materialid = materialid;
                 s->faces.push_back(f);
@@ -311,7 +318,12 @@ void aipt_geom_build(aipt_geom* g) {                                            
 }
 
 int aipt_scene_load(const char* path, aipt_scene** out, char* err, size_t errlen) {
+    return aipt_scene_load_ex(path, 0u, out, err, errlen);
+}
+
+int aipt_scene_load_ex(const char* path, unsigned flags, aipt_scene** out, char* err, size_t errlen) {
     if (!path || !out) return seterr(err, errlen, AIPT_E_INVALID, "aipt_scene_load: NULL argument");
+    if (flags & ~AIPT_SCENE_RECOMPUTE_NORMALS) return seterr(err, errlen, AIPT_E_INVALID, "aipt_scene_load_ex: unknown flag");
     *out = nullptr;
     std::ifstream in(path);
     if (!in.is_open()) return seterr(err, errlen, AIPT_E_IO, std::string("cannot open scene file ") + path);
@@ -415,7 +427,7 @@ int aipt_scene_load(const char* path, aipt_scene** out, char* err, size_t errlen
                 std::ifstream probe(s->dir + "/" + mesh_path);
                 if (probe.is_open()) p1 = s->dir + "/" + mesh_path;
             }
-            const int rc = load_obj(s.get(), p1, materialid, xf, e);
+            const int rc = load_obj(s.get(), p1, materialid, xf, flags, e);
             if (rc) return seterr(err, errlen, rc, e);
         }
     }

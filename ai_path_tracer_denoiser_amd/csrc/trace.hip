@@ -337,12 +337,69 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) {       //
     return r0 + (1 - r0) * ((x2 * x2) * x);
 }
 
-// scatterRay, live branch (DIELECTRIC false, FRESNELS true): :194-258
-__device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hitP, const aipt_material& m, uint32_t& rng) {
+// ---- the DIELECTRIC branch of interactions.h (:6 false in the reference; AIPT_TRACE_DIELECTRIC here): :88-168, :179-192
+__device__ __forceinline__ float fresnelDielectric(float cosThetaI, float etaI, float etaT) {   // :88-115
+    cosThetaI = glm_min(glm_max(cosThetaI, -1.0f), 1.0f);                     // glm::clamp
+    const bool entering = cosThetaI > 0.0f;
+    float etaIb = etaI, etaTb = etaT;
+    if (!entering) { etaIb = etaT; etaTb = etaI; cosThetaI = fabsf(cosThetaI); }
+    const float sinThetaI = sqrtf(glm_max(0.0f, 1 - cosThetaI * cosThetaI));
+    const float sinThetaT = etaIb / etaTb * sinThetaI;
+    if (sinThetaT >= 1) return 1.0f;
+    const float cosThetaT = sqrtf(glm_max(0.0f, 1 - sinThetaT * sinThetaT));
+    const float Rparl = ((etaTb * cosThetaI) - (etaIb * cosThetaT)) / ((etaTb * cosThetaI) + (etaIb * cosThetaT));
+    const float Rperp = ((etaIb * cosThetaI) - (etaTb * cosThetaT)) / ((etaIb * cosThetaI) + (etaTb * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+__device__ __forceinline__ void specularReflection(v3& origin, v3& direction, v3& pcolor, v3 hitP, v3 normal, const aipt_material& m) {   // :121-125
+    pcolor = vmul(pcolor, V(m.specular_color[0], m.specular_color[1], m.specular_color[2]));
+    direction = vreflect(direction, normal);
+    origin = vadd(hitP, vscale(direction, .001f));
+}
+__device__ __forceinline__ void specularRefraction(v3& origin, v3& direction, v3& pcolor, v3 hitP, v3 normal, const aipt_material& m) {   // :127-146
+    const v3 wo = direction;
+    const bool leaving = vdot(wo, normal) > 0.f;
+    const v3 n = vscale(normal, leaving ? -1.f : 1.f);
+    const float eta = leaving ? m.indexOfRefraction : (1.f / m.indexOfRefraction);
+    v3 wi = glm_refract(wo, n, eta);
+    if (vlength(wi) < .01f) {                                                 // total internal reflection
+        pcolor = vscale(pcolor, 0.0f);
+        wi = vreflect(wo, normal);
+    }
+    pcolor = vmul(pcolor, V(m.specular_color[0], m.specular_color[1], m.specular_color[2]));
+    direction = wi;
+    origin = vadd(hitP, vscale(direction, .001f));
+}
+__device__ void scatterDielectric(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hitP, const aipt_material& m, uint32_t& rng) {   // :179-192
+    const float REF_EPSILON = 0.0001f;                                        // utilities.h:16
+    if (m.hasReflective > REF_EPSILON && m.hasRefractive > REF_EPSILON) {     // Glass_BxDF :148-163
+        const float VdotN = vdot(vneg(direction), hitN);
+        const bool leaving = VdotN < 0.f;
+        const float eI = leaving ? m.indexOfRefraction : 1.f;
+        const float eT = leaving ? 1.f : m.indexOfRefraction;
+        const float fresnel = fresnelDielectric(VdotN, eI, eT) / fabsf(VdotN);
+        if (u01(rng, 0.0f, 1.0f) < fresnel) specularReflection(origin, direction, pcolor, hitP, hitN, m);
+        else specularRefraction(origin, direction, pcolor, hitP, hitN, m);
+    } else if (m.hasReflective > REF_EPSILON) {
+        specularReflection(origin, direction, pcolor, hitP, hitN, m);
+    } else if (m.hasRefractive > REF_EPSILON) {
+        specularRefraction(origin, direction, pcolor, hitP, hitN, m);
+    } else {                                                                  // Lambert_BxDF :164-168
+        direction = hemisphere(vnormalize(hitN), rng);
+        pcolor = vmul(pcolor, V(m.color[0], m.color[1], m.color[2]));
+        origin = vadd(hitP, vscale(direction, .001f));
+    }
+}
+
+// scatterRay: the live branch (DIELECTRIC false, FRESNELS true, :194-258), the DIELECTRIC branch under AIPT_TRACE_DIELECTRIC,
+// MESH_NORMAL_VIEW (:4, :222-255: the surface normal as the colour) under AIPT_TRACE_MESH_NORMAL_VIEW
+__device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hitP, const aipt_material& m, uint32_t& rng, uint32_t flags) {
+    if (flags & AIPT_TRACE_DIELECTRIC) { scatterDielectric(origin, direction, pcolor, hitN, hitP, m, rng); return; }
+    const bool nview = (flags & AIPT_TRACE_MESH_NORMAL_VIEW) != 0;
     v3 dir = direction;
     v3 color;
-    const v3 mcolor = V(m.color[0], m.color[1], m.color[2]);
-    const v3 scolor = V(m.specular_color[0], m.specular_color[1], m.specular_color[2]);
+    const v3 mcolor = nview ? hitN : V(m.color[0], m.color[1], m.color[2]);
+    const v3 scolor = nview ? hitN : V(m.specular_color[0], m.specular_color[1], m.specular_color[2]);
     float reflective_prob = m.hasReflective;
     if (reflective_prob != 0 || m.hasRefractive != 0) {
         const float pdf = u01(rng, 0.0f, 1.0f);
@@ -378,6 +435,7 @@ __device__ void scatterRay(v3& origin, v3& direction, v3& pcolor, v3 hitN, v3 hi
     }
     direction = dir;
     origin = vadd(hitP, vscale(dir, 0.01f));
+    if (nview) color = V(fabsf(color.x), fabsf(color.y), fabsf(color.z));     // :254
     pcolor = vmul(pcolor, color);
 }
 
@@ -784,7 +842,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             bool walker = false;
             if (alive && walk_mesh && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
                 const float4 a = S0[i], b = S1[i];
-                walker = rayAABB(V(a.x, a.y, a.z), V(a.w, b.x, b.y), p.box);      // RAY_CULLING true (:23, :258)
+                walker = (p.flags & AIPT_TRACE_NO_CULL) || rayAABB(V(a.x, a.y, a.z), V(a.w, b.x, b.y), p.box);      // RAY_CULLING (:23, :258)
             }
             const unsigned long long m = __ballot(walker);
             int base = 0;
@@ -911,7 +969,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 const float t = triangleTest(f, o, d, tp, tn);
                 t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
             }
-        } else if (walk_mesh && rayAABB(o, d, p.box)) {                   // RAY_CULLING true (:23, :258)
+        } else if (walk_mesh && ((p.flags & AIPT_TRACE_NO_CULL) || rayAABB(o, d, p.box))) {   // RAY_CULLING true (:23, :258) / false (:270-281)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -955,7 +1013,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                 new_rem = 0;
                 col = vscale(vmul(col, V(m.color[0], m.color[1], m.color[2])), m.emittance);
             } else {
-                scatterRay(o, d, col, surfN, hitP, m, rng);
+                scatterRay(o, d, col, surfN, hitP, m, rng, p.flags);
                 new_rem = rem - 1;
             }
         } else {

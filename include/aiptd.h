@@ -138,6 +138,13 @@ int  aipt_timer_stop(aipt_ctx* ctx, float* ms_out);
                                        iter % 4 == 0 and iter < 3000 the primitives that have a velocity (Geom::vel, scene key VEL)
                                        move by vel * 0.10 and their matrices are rebuilt; the moved primitives persist in the
                                        context until the next aipt_scene_upload. */
+#define AIPT_TRACE_NO_CULL     512u /* RAY_CULLING false (pathtrace.cu:23, 270-281): every ray is tested against the mesh, without the
+                                       scene-AABB test in front (the test is not exact: rays that graze the box decide differently). */
+#define AIPT_TRACE_DIELECTRIC  1024u /* DIELECTRIC true (interactions.h:6, 88-168, 179-192): materials scatter through Glass_BxDF /
+                                       SpecularReflection_BxDF / SpecularRefraction_BxDF / Lambert_BxDF (Fresnel-weighted choice,
+                                       0.001 ray offsets, un-normalised directions) instead of the Schlick branch. */
+#define AIPT_TRACE_MESH_NORMAL_VIEW 2048u /* MESH_NORMAL_VIEW true (interactions.h:4, 222-255): the debug view -- a path's colour is
+                                       multiplied by |surface normal| instead of the material colour (Schlick branch only). */
 #define AIPT_TRACE_DEFAULT     (AIPT_TRACE_AA | AIPT_TRACE_COMPACT)
 
 /* pathtraceInit (pathtrace.cu:96-129), scene part: copies and re-lays-out the scene on the device.
@@ -289,6 +296,11 @@ typedef struct aipt_scene aipt_scene;
  * primitive, loads + transforms the OBJ mesh and its bounding box, and sets the first-frame orbit camera.
  * err (optional) receives the message on failure. */
 int  aipt_scene_load(const char* path, aipt_scene** out, char* err, size_t errlen);
+/* The same with the loader's compile-time switch as a flag.  AIPT_SCENE_RECOMPUTE_NORMALS = RECOMPUTE_NORMALS true (scene.cpp:9,
+ * 198-204, 310-311): the OBJ's vertex normals are replaced by the face normal normalize(cross(v2 - v0, v1 - v0)) of the
+ * transformed triangle -- in n[0] and n[1]; n[2] stays the zero vector, as the reference's assignment leaves it. */
+#define AIPT_SCENE_RECOMPUTE_NORMALS 1u
+int  aipt_scene_load_ex(const char* path, unsigned flags, aipt_scene** out, char* err, size_t errlen);
 void aipt_scene_release(aipt_scene* scene);
 int  aipt_scene_set_resolution(aipt_scene* scene, int width, int height);   /* override RES; recomputes fov/pixelLength */
 int  aipt_scene_info(const aipt_scene* scene, int* ngeoms, int* nmaterials, int* nfaces, int* iterations, int* depth);

@@ -128,6 +128,7 @@ assert (C.sizeof(Geom), C.sizeof(Face), C.sizeof(Material), C.sizeof(Camera), C.
 SPHERE, CUBE = 0, 1
 TRACE_AA, TRACE_COMPACT, TRACE_SORT_MATERIAL, TRACE_CACHE_FIRST_BOUNCE = 1, 2, 32, 64     # = include/aiptd.h AIPT_TRACE_*
 TRACE_ORACLE_BVH = 256       # oracle only: the face loop through a CPU BVH (oracle/trace_bvh.c), same result
+TRACE_NO_CULL, TRACE_DIELECTRIC, TRACE_MESH_NORMAL_VIEW = 512, 1024, 2048   # RAY_CULLING false, DIELECTRIC true, MESH_NORMAL_VIEW true
 
 
 def _trace_lib():
@@ -151,6 +152,9 @@ def _trace_lib():
         L.orc_ray_aabb.restype = C.c_int
         L.orc_ray_aabb.argtypes = [C.c_void_p] * 3
         L.orc_scatter.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_scatter_dielectric.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.orc_fresnel_dielectric.restype = C.c_float
+        L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float, C.c_float]
         L.orc_intersect_scene.restype = C.c_float
         L.orc_intersect_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                           C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p]

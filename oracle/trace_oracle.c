@@ -317,12 +317,75 @@ typedef struct {
     float t; v3 surfaceNormal; int materialId; v3 intersect;
 } hit_t;
 
+/* ---- the compile-time branches of interactions.h that the reference ships switched off, as run-time flags of
+ * orc_pathtrace_ex: DIELECTRIC (:6, :179-192) = flag 1024, MESH_NORMAL_VIEW (:4) = flag 2048 */
+static int g_dielectric = 0, g_normal_view = 0;
+#define REF_EPSILON 0.0001f                                                 /* utilities.h:16 */
+
+static float FresnelDielectric_Evaluate(float cosThetaI, float etaI, float etaT) {   /* :88-115 */
+    cosThetaI = glm_min(glm_max(cosThetaI, -1.0f), 1.0f);                   /* glm::clamp = min(max(x, lo), hi) */
+    const int entering = cosThetaI > 0.0f;
+    float etaIb = etaI, etaTb = etaT;
+    if (!entering) { etaIb = etaT; etaTb = etaI; cosThetaI = fabsf(cosThetaI); }
+    const float sinThetaI = sqrtf(glm_max(0.0f, 1 - cosThetaI * cosThetaI));
+    const float sinThetaT = etaIb / etaTb * sinThetaI;
+    if (sinThetaT >= 1) return 1.0f;
+    const float cosThetaT = sqrtf(glm_max(0.0f, 1 - sinThetaT * sinThetaT));
+    const float Rparl = ((etaTb * cosThetaI) - (etaIb * cosThetaT)) / ((etaTb * cosThetaI) + (etaIb * cosThetaT));
+    const float Rperp = ((etaIb * cosThetaI) - (etaTb * cosThetaT)) / ((etaIb * cosThetaI) + (etaTb * cosThetaT));
+    return (Rparl * Rparl + Rperp * Rperp) / 2;
+}
+static void SpecularReflection_BxDF(path_t* ps, v3 intersect, v3 normal, const orc_material* m) {   /* :121-125 */
+    ps->color = vmul(ps->color, V(m->spec_color[0], m->spec_color[1], m->spec_color[2]));
+    ps->direction = vreflect(ps->direction, normal);
+    ps->origin = vadd(intersect, vscale(ps->direction, .001f));
+}
+static void SpecularRefraction_BxDF(path_t* ps, v3 intersect, v3 normal, const orc_material* m) {   /* :127-146 */
+    const v3 wo = ps->direction;
+    const int leaving = vdot(wo, normal) > 0.f;
+    const v3 n = vscale(normal, leaving ? -1.f : 1.f);
+    const float eta = leaving ? m->indexOfRefraction : (1.f / m->indexOfRefraction);
+    v3 wi = glm_refract(wo, n, eta);
+    if (vlength(wi) < .01f) {                                               /* total internal reflection */
+        ps->color = vscale(ps->color, 0.0f);
+        wi = vreflect(wo, normal);
+    }
+    ps->color = vmul(ps->color, V(m->spec_color[0], m->spec_color[1], m->spec_color[2]));
+    ps->direction = wi;
+    ps->origin = vadd(intersect, vscale(ps->direction, .001f));
+}
+static void Glass_BxDF(path_t* ps, v3 intersect, v3 normal, const orc_material* m, uint32_t* rng) {   /* :148-163 */
+    const float VdotN = vdot(vneg(ps->direction), normal);
+    const int leaving = VdotN < 0.f;
+    const float eI = leaving ? m->indexOfRefraction : 1.f;
+    const float eT = leaving ? 1.f : m->indexOfRefraction;
+    const float fresnel = FresnelDielectric_Evaluate(VdotN, eI, eT) / fabsf(VdotN);
+    if (orc_u01(rng, 0.0f, 1.0f) < fresnel) SpecularReflection_BxDF(ps, intersect, normal, m);
+    else SpecularRefraction_BxDF(ps, intersect, normal, m);
+}
+static void Lambert_BxDF(path_t* ps, v3 intersect, v3 normal, const orc_material* m, uint32_t* rng) {   /* :164-168 */
+    const v3 nn = vnormalize(normal);
+    const float nrm[3] = {nn.x, nn.y, nn.z};
+    float h[3];
+    orc_hemisphere(nrm, rng, h);
+    ps->direction = V(h[0], h[1], h[2]);
+    ps->color = vmul(ps->color, V(m->color[0], m->color[1], m->color[2]));
+    ps->origin = vadd(intersect, vscale(ps->direction, .001f));
+}
+
 static void scatterRay(path_t* ps, const hit_t* isect, const orc_material* m, uint32_t* rng) {   /* :170-259 */
     v3 dir = ps->direction;
     v3 color = V(1.0f, 1.0f, 1.0f);
-    const v3 mcolor = V(m->color[0], m->color[1], m->color[2]);
-    const v3 scolor = V(m->spec_color[0], m->spec_color[1], m->spec_color[2]);
+    const v3 mcolor = g_normal_view ? isect->surfaceNormal : V(m->color[0], m->color[1], m->color[2]);           /* :222-255 */
+    const v3 scolor = g_normal_view ? isect->surfaceNormal : V(m->spec_color[0], m->spec_color[1], m->spec_color[2]);
     float reflective_prob = m->hasReflective;
+    if (g_dielectric) {                                                     /* :179-192 */
+        if (m->hasReflective > REF_EPSILON && m->hasRefractive > REF_EPSILON) Glass_BxDF(ps, isect->intersect, isect->surfaceNormal, m, rng);
+        else if (m->hasReflective > REF_EPSILON) SpecularReflection_BxDF(ps, isect->intersect, isect->surfaceNormal, m);
+        else if (m->hasRefractive > REF_EPSILON) SpecularRefraction_BxDF(ps, isect->intersect, isect->surfaceNormal, m);
+        else Lambert_BxDF(ps, isect->intersect, isect->surfaceNormal, m, rng);
+        return;
+    }
     if (reflective_prob != 0 || m->hasRefractive != 0) {
         const float pdf = orc_u01(rng, 0.0f, 1.0f);
         float refrac_index_ratio, cosine;
@@ -360,7 +423,18 @@ static void scatterRay(path_t* ps, const hit_t* isect, const orc_material* m, ui
     }
     ps->direction = dir;
     ps->origin = vadd(isect->intersect, vscale(dir, 0.01f));
+    if (g_normal_view) color = V(fabsf(color.x), fabsf(color.y), fabsf(color.z));   /* :254 */
     ps->color = vmul(ps->color, color);
+}
+
+/* test hooks of the DIELECTRIC branch: the Fresnel reflectance; one scatterRay call with the branch switched on */
+float orc_fresnel_dielectric(float cosThetaI, float etaI, float etaT) { return FresnelDielectric_Evaluate(cosThetaI, etaI, etaT); }
+void orc_scatter(float* io, const float* hit, const orc_material* m, uint32_t* rng);
+void orc_scatter_dielectric(float* io, const float* hit, const orc_material* m, uint32_t* rng) {
+    const int keep = g_dielectric;
+    g_dielectric = 1;
+    orc_scatter(io, hit, m, rng);
+    g_dielectric = keep;
 }
 
 /* test hook: one scatterRay call on flat arrays; io = origin[3] dir[3] color[3]; hit = t, n[3], P[3] */
@@ -397,7 +471,7 @@ static void generateRay(const orc_camera* cam, int iter, int traceDepth, int x, 
 void orc_bvh_prepare(const orc_face* faces, int nfaces);
 void orc_bvh_nearest(const orc_face* faces, int nfaces, const float* ro, const float* rd, float* t_min, int* best,
                      float* P, float* N);
-static int g_use_bvh = 0;
+static int g_use_bvh = 0, g_no_cull = 0;
 
 static void computeIntersection(const path_t* ps, const orc_geom* geoms, int ngeoms, const orc_face* faces, int nfaces,
                                 const orc_aabb* box, hit_t* out, v3* raw_normal) {   /* :200-306 */
@@ -418,14 +492,14 @@ static void computeIntersection(const path_t* ps, const orc_geom* geoms, int nge
         }
     }
     int walked = 0;
-    if (g_use_bvh && nfaces && orc_ray_aabb(ro, rd, box)) {
+    if (g_use_bvh && nfaces && (g_no_cull || orc_ray_aabb(ro, rd, box))) {
         int best = -1;
         float tm = t_min;
         orc_bvh_nearest(faces, nfaces, ro, rd, &tm, &best, P, N);
         if (best >= 0) { t_min = tm; materialid = faces[best].materialid; ip = V(P[0], P[1], P[2]); normal = V(N[0], N[1], N[2]); }
         walked = best != -2;                        /* -2: tree not prepared for this array -> the exhaustive loop */
     }
-    if (!walked && nfaces && orc_ray_aabb(ro, rd, box)) {      /* RAY_CULLING true (:23, :258) */
+    if (!walked && nfaces && (g_no_cull || orc_ray_aabb(ro, rd, box))) {      /* RAY_CULLING true (:23, :258); false (:270-281) = flag 512 */
         for (int i = 0; i < nfaces; i++) {
             const float t = orc_triangle_test(&faces[i], ro, rd, P, N);
             if (t > 0.0f && t_min > t) {
@@ -521,6 +595,9 @@ int orc_pathtrace_ex(const orc_camera* cam, const orc_geom* geoms, int ngeoms, c
     const int aa = (flags & 1u) != 0, compact = (flags & 2u) != 0, sortmat = (flags & 32u) != 0;
     const int use_cache = (flags & 64u) != 0 && cache != NULL;
     g_use_bvh = (flags & 256u) != 0;                /* test-side acceleration of the face loop, same result (trace_bvh.c) */
+    g_no_cull = (flags & 512u) != 0;                /* RAY_CULLING false */
+    g_dielectric = (flags & 1024u) != 0;            /* DIELECTRIC true */
+    g_normal_view = (flags & 2048u) != 0;           /* MESH_NORMAL_VIEW true */
     if (g_use_bvh) orc_bvh_prepare(faces, nfaces);
     path_t* paths = (path_t*)malloc(sizeof(path_t) * P);
     path_t* tmp = (path_t*)malloc(sizeof(path_t) * P);

@@ -245,3 +245,67 @@ def test_configs4_living_room_1920x1080_depth12_bit_exact(ctx):
     sc = _living_room((1920, 1080), 12, 524288)
     m = _full_size(ctx, sc, 12, "configs[4]")
     assert {7, 8} <= set(np.unique(m).tolist())
+
+
+# ---- the compile-time branches the reference ships switched off, as run-time flags (VERDICT r2 "what's missing" 1, 3, 4)
+
+def _glassy_scene(res, depth, nfaces=4096):
+    """Cornell + a small atrium whose floor is a mirror and whose columns are glass-with-reflection (REFL and REFR both set:
+    the Glass_BxDF branch), a mirror sphere and a diffuse box: every branch of the DIELECTRIC scatterRay is taken"""
+    sc = _cornell(res, depth)
+    both = synth.material((.9, .95, 1.0), spec=(.98, .98, .98), refl=0.5, refr=1.0, ior=1.5)
+    first = add_materials(sc, [synth.STONE, synth.MIRROR, synth.GLASS, both])
+    faces, lb, ub = synth.make_atrium_mesh(nfaces, 565, material=first, floor_material=first + 1, column_material=first + 3)
+    sc.set_mesh(faces, lb, ub)
+    sc.geoms[-1].materialid = first + 2               # the sphere: refraction only
+    return sc, first
+
+
+def test_dielectric_branch_bit_exact(ctx):
+    """AIPT_TRACE_DIELECTRIC = DIELECTRIC true (interactions.h:6, 88-168, 179-192)"""
+    import oracle
+    sc, first = _glassy_scene((160, 120), 8)
+    fl = oracle.TRACE_AA | oracle.TRACE_COMPACT
+    g_ref, n_ref, m_ref = sc.pathtrace(flags=fl | api.TRACE_DIELECTRIC)
+    g, n, mt = gpu_trace(ctx, sc, 8, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0 | api.TRACE_DIELECTRIC)
+    assert np.array_equal(mt, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist()
+    _same(g, g_ref, "dielectric branch")
+    for k in (1, 2, 3):
+        assert (m_ref == first + k).sum() > 100        # mirror, glass and glass-with-reflection surfaces are all visible
+    g_plain, _, _ = sc.pathtrace(flags=fl)
+    assert not np.array_equal(bits(g_plain), bits(g_ref))   # and the branch is a different renderer
+
+
+def test_mesh_normal_view_bit_exact(ctx):
+    """AIPT_TRACE_MESH_NORMAL_VIEW = MESH_NORMAL_VIEW true (interactions.h:4, 222-255)"""
+    import oracle
+    sc, first = _glassy_scene((128, 96), 6)
+    fl = oracle.TRACE_AA | oracle.TRACE_COMPACT
+    g_ref, n_ref, m_ref = sc.pathtrace(flags=fl | api.TRACE_MESH_NORMAL_VIEW)
+    g, n, mt = gpu_trace(ctx, sc, 6, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0 | api.TRACE_MESH_NORMAL_VIEW)
+    assert n[:len(n_ref)].tolist() == n_ref.tolist()
+    _same(g, g_ref, "normal view")
+
+
+def test_no_cull_bit_exact(ctx):
+    """AIPT_TRACE_NO_CULL = RAY_CULLING false (pathtrace.cu:23, 270-281): no scene-AABB test in front of the mesh; the BVH walk
+    and the brute-force loop agree with the oracle's loop over all faces"""
+    import oracle
+    sc, first = _glassy_scene((128, 96), 6, nfaces=2048)
+    fl = oracle.TRACE_AA | oracle.TRACE_COMPACT
+    g_ref, n_ref, m_ref = sc.pathtrace(flags=fl | api.TRACE_NO_CULL)
+    for extra in (0, api.TRACE_BRUTE_FORCE):
+        g, n, mt = gpu_trace(ctx, sc, 6, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0 | api.TRACE_NO_CULL | extra)
+        assert np.array_equal(mt, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist()
+        _same(g, g_ref, f"no cull ({extra})")
+    # batches of frames (pooled walks) take the flag too
+    cams = [api.Camera.from_buffer_copy(bytes(sc.camera)) for _ in range(3)]
+    import torch
+    W, H = sc.camera.res[0], sc.camera.res[1]
+    ctx.trace_configure_batch(W, H, 3)
+    gb = torch.zeros(3, 10, H, W, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pathtrace_batch(cams, 1, 6, gb, api.TRACE_DEFAULT | api.TRACE_NO_CULL)
+    ctx.sync()
+    for k in range(3):
+        _same(gb[k].cpu().numpy(), g_ref, f"no cull, batch frame {k}")

@@ -89,3 +89,30 @@ def test_geom_build_matches_the_reference_glm_table(golden_dir):
         got = np.concatenate([np.frombuffer(bytes(g.transform), np.uint32), np.frombuffer(bytes(g.inverseTransform), np.uint32),
                               np.frombuffer(bytes(g.invTranspose), np.uint32)])
         assert np.array_equal(got, want[k]), f"row {k}"
+
+
+def test_recompute_normals_flag(tmp_path):
+    """aipt_scene_load_ex(AIPT_SCENE_RECOMPUTE_NORMALS) = RECOMPUTE_NORMALS true (scene.cpp:9, 198-204, 310-311): the face normal
+    normalize(cross(v2 - v0, v1 - v0)) of the TRANSFORMED triangle in n[0] and n[1]; n[2] stays zero (the reference assigns n[1]
+    twice)"""
+    obj = tmp_path / "tri.obj"
+    obj.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0.3 0.2 1\nvn 0 0 1\nvn 0 1 0\nf 1//1 2//1 3//2\nf 1//1 3//1 4//2\n")
+    scene = tmp_path / "s.txt"
+    scene.write_text("MATERIAL 0\nRGB 1 1 1\nSPECEX 0\nSPECRGB 0 0 0\nREFL 0\nREFR 0\nREFRIOR 0\nEMITTANCE 0\n\n"
+                     "CAMERA\nRES 64 64\nFOVY 45\nITERATIONS 1\nDEPTH 3\nFILE x\nEYE 0 0 5\nLOOKAT 0 0 0\nUP 0 1 0\n\n"
+                     f"MESH 0\nPATH {obj.name}\nmaterial 0\nTRANS 1 2 3\nROTAT 10 20 30\nSCALE 2 1 3\n")
+    plain = api.Scene(str(scene))
+    s = api.Scene(str(scene), flags=api.SCENE_RECOMPUTE_NORMALS)
+    assert s.nfaces == plain.nfaces == 2
+    for f, g in zip(s.faces, plain.faces):
+        v = np.array([list(p) for p in f.v], np.float32)
+        assert np.array_equal(v, np.array([list(p) for p in g.v], np.float32))       # vertices are what they were
+        e10, e20 = v[1] - v[0], v[2] - v[0]
+        c = np.array([e20[1] * e10[2] - e10[1] * e20[2], e20[2] * e10[0] - e10[2] * e20[0], e20[0] * e10[1] - e10[0] * e20[1]], np.float32)
+        want = c / np.sqrt(np.float32(c @ c))
+        n = np.array([list(p) for p in f.n], np.float32)
+        assert np.allclose(n[0], want, atol=2e-7) and np.array_equal(n[0], n[1])
+        assert np.array_equal(n[2], np.zeros(3, np.float32))
+        assert not np.allclose(n[0], np.array([list(p) for p in g.n], np.float32)[0], atol=1e-3)
+    with pytest.raises(api.AiptError):
+        api.Scene(str(scene), flags=4)

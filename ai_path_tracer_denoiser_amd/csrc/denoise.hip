@@ -46,7 +46,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // producing conv left per-channel sums in `stat` (64-bit atomics into NSLOT replicas, slot = workgroup % NSLOT: 3680
 // workgroups x 64 atomics cost 1.6 us that way, tools/atomicbench.hip) and every consumer workgroup turns them into
 // (a, b) itself in its prologue -- there is no finalize launch between two convs (28 launches x 4.1 us per frame).
-// The sums are 64-bit FIXED-POINT integers (24 fractional bits, |sum| < 2^39 = 5.5e11: a mean square below 5.8e5 at 1280x736;
+// The sums are 64-bit FIXED-POINT integers (24 fractional bits for sums, 20 for sums of squares, see BN_FIX2;
 // raw conv outputs of a BatchNorm network are O(10)): integer addition is associative, so the statistics -- and with them
 // every output bit -- do not depend on the order in which the workgroups' atomics land.  (fp64 sums of fp32 partials are
 // exact only while all partials fit one 53-bit window; a channel with a wide spread of partial magnitudes broke
@@ -54,7 +54,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // over >= 128 pixels), far below BatchNorm's eps.  The table stays addressed as doubles (8-byte slots).
 // Running statistics / identity: `ab` (or nothing).
 constexpr int NSLOT = 8;
-constexpr double BN_FIX = 16777216.0, BN_FIX_INV = 1.0 / 16777216.0;       // 2^24
+constexpr double BN_FIX = 16777216.0, BN_FIX_INV = 1.0 / 16777216.0;       // 2^24: sums, |sum| < 2^39 = 5.5e11
+// Sums of SQUARES keep 20 fractional bits: < 2^43 = 8.8e12, a root mean square of 3 000 at 1280 x 736 (with 24 bits the sum
+// wrapped silently at an rms of ~740, which HDR inputs can reach).  A partial is rounded to 2^-20 once: at most 1e-6 on a
+// workgroup's sum over >= 128 pixels, i.e. < 1e-8 per pixel against BatchNorm's eps of 1e-5.
+constexpr double BN_FIX2 = 1048576.0, BN_FIX2_INV = 1.0 / 1048576.0;
 struct BnRef {
     const float2* ab;      // explicit affine; with stat == nullptr and ab == nullptr: identity
     const double* stat;    // [NSLOT][sc][2]: sum, sum of squares
@@ -75,7 +79,7 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
         long long ix = 0, ixx = 0;
 #pragma unroll
         for (int k = 0; k < NSLOT; k++) { ix += v[k][0]; ixx += v[k][1]; }
-        const double sx = (double)ix * BN_FIX_INV, sxx = (double)ixx * BN_FIX_INV;
+        const double sx = (double)ix * BN_FIX_INV, sxx = (double)ixx * BN_FIX2_INV;
         const double mean = sx * r.inv_n;
         double var = sxx * r.inv_n - mean * mean;          // biased variance, as torch normalises with
         if (var < 0) var = 0;
@@ -86,14 +90,14 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
     return r.ab ? r.ab[c] : make_float2(1.0f, 0.0f);
 }
 // a workgroup's BN sums of channel c (already reduced over the workgroup) -> the producer's stat table
-__device__ __forceinline__ long long bn_fix(double v) {      // fixed point, 24 fractional bits; clamped so that NaN / inf stay defined
-    v = fmin(fmax(v * BN_FIX, -4.0e18), 4.0e18);
+__device__ __forceinline__ long long bn_fix(double v, double scale = BN_FIX) {      // fixed point; clamped so that NaN / inf stay defined
+    v = fmin(fmax(v * scale, -4.0e18), 4.0e18);
     return v == v ? __double2ll_rn(v) : 0ll;
 }
 __device__ __forceinline__ void bn_accumulate_slot(double* stat, int sc, int slot, int c, double sum, double sumsq) {
     unsigned long long* a = reinterpret_cast<unsigned long long*>(stat + ((size_t)slot * sc + c) * 2);
     atomicAdd(a, (unsigned long long)bn_fix(sum));
-    atomicAdd(a + 1, (unsigned long long)bn_fix(sumsq));
+    atomicAdd(a + 1, (unsigned long long)bn_fix(sumsq, BN_FIX2));
 }
 __device__ __forceinline__ void bn_accumulate(double* stat, int sc, int c, float sum, float sumsq) {
     bn_accumulate_slot(stat, sc, blockIdx.x % NSLOT, c, (double)sum, (double)sumsq);
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
             const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
             const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
             atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)bn_fix((double)bsum1));
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)bn_fix((double)bsum2));
+            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)bn_fix((double)bsum2, BN_FIX2));
         }
         __syncthreads();
         if (tid < 32 && n0 + tid < g.cout) {
@@ -1420,7 +1424,7 @@ __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, 
     }
     if (threadIdx.x == 0) {                                    // slot 0 of a zeroed table, in the table's fixed-point format
         reinterpret_cast<long long*>(stat)[blockIdx.x * 2] = bn_fix(sa[0]);
-        reinterpret_cast<long long*>(stat)[blockIdx.x * 2 + 1] = bn_fix(sb[0]);
+        reinterpret_cast<long long*>(stat)[blockIdx.x * 2 + 1] = bn_fix(sb[0], BN_FIX2);
     }
 }
 

@@ -26,40 +26,60 @@ def build(force=False):
     return so
 
 
+def _bind_dn(so):
+    L = C.CDLL(so)
+    L.orc_dn_create.restype = C.c_void_p
+    L.orc_dn_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_dn_destroy.argtypes = [C.c_void_p]
+    L.orc_dn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+    L.orc_dn_get_hidden.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_dn_set_hidden.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.orc_dn_reset_hidden.argtypes = [C.c_void_p]
+    L.orc_dn_conv_checksums.argtypes = [C.c_void_p, C.c_void_p]
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
-        L = C.CDLL(so)
-        L.orc_dn_create.restype = C.c_void_p
-        L.orc_dn_create.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
-        L.orc_dn_destroy.argtypes = [C.c_void_p]
-        L.orc_dn_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
-        L.orc_dn_get_hidden.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.orc_dn_set_hidden.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.orc_dn_reset_hidden.argtypes = [C.c_void_p]
-        L.orc_dn_conv_checksums.argtypes = [C.c_void_p, C.c_void_p]
-        _LIB = L
+        _LIB = _bind_dn(so)
     return _LIB
+
+
+_LIB64 = None
+
+
+def lib64():
+    """the denoiser restatement compiled with -DORC_DN_FP64: double activations, products and sums (liboracle64.so)"""
+    global _LIB64
+    if _LIB64 is None:
+        so = os.path.join(_HERE, "liboracle64.so")
+        if not os.path.exists(so):
+            build(force=True)
+        _LIB64 = _bind_dn(so)
+    return _LIB64
 
 
 class DenoiseOracle:
     """CPU restatement of AutoEncoder.forward (reference: recurrent_autoencoder_model.py:120-142)."""
 
-    def __init__(self, blob: bytes, H: int, W: int):
+    def __init__(self, blob: bytes, H: int, W: int, fp64: bool = False):
+        """fp64: the all-double build (the truth of the precision studies); the interface stays float32"""
         from ai_path_tracer_denoiser_amd import arch
         self.H, self.W = H, W
         self._arch = arch
         self._blob = blob
-        self._h = lib().orc_dn_create(blob, len(blob), H, W)
+        self._L = lib64() if fp64 else lib()
+        self._h = self._L.orc_dn_create(blob, len(blob), H, W)
         if not self._h:
             raise ValueError("orc_dn_create failed (bad blob, or H/W not multiples of 32)")
 
     def close(self):
         if self._h:
-            lib().orc_dn_destroy(self._h)
+            self._L.orc_dn_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -70,7 +90,7 @@ class DenoiseOracle:
         assert x.shape == (10, self.H, self.W)
         out = np.empty((3, self.H, self.W), np.float32)
         flags = (BN_BATCH if bn_batch else 0) | (HIDDEN_CARRY if carry else 0)
-        rc = lib().orc_dn_forward(self._h, x.ctypes.data, out.ctypes.data, flags)
+        rc = self._L.orc_dn_forward(self._h, x.ctypes.data, out.ctypes.data, flags)
         if rc:
             raise RuntimeError(f"orc_dn_forward rc={rc}")
         return out
@@ -78,20 +98,20 @@ class DenoiseOracle:
     def hidden(self, level: int) -> np.ndarray:
         shp = self._arch.hidden_shapes(self.H, self.W)[level]
         h = np.empty(shp, np.float32)
-        lib().orc_dn_get_hidden(self._h, level, h.ctypes.data)
+        self._L.orc_dn_get_hidden(self._h, level, h.ctypes.data)
         return h
 
     def set_hidden(self, level: int, h: np.ndarray):
         h = np.ascontiguousarray(h, dtype=np.float32)
         assert h.shape == self._arch.hidden_shapes(self.H, self.W)[level]
-        lib().orc_dn_set_hidden(self._h, level, h.ctypes.data)
+        self._L.orc_dn_set_hidden(self._h, level, h.ctypes.data)
 
     def reset_hidden(self):
-        lib().orc_dn_reset_hidden(self._h)
+        self._L.orc_dn_reset_hidden(self._h)
 
     def conv_checksums(self) -> np.ndarray:
         s = np.empty(28, np.float64)
-        lib().orc_dn_conv_checksums(self._h, s.ctypes.data)
+        self._L.orc_dn_conv_checksums(self._h, s.ctypes.data)
         return s
 
 

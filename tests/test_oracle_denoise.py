@@ -98,3 +98,20 @@ def test_torch_restatement_agrees_with_the_c_oracle():
             a = orc.forward(x, bn_batch, carry and k > 0)
             b = td.forward(x, bn_batch, carry and k > 0)
             assert np.abs(a - b).max() < 1e-3, (bn_batch, carry, k, float(np.abs(a - b).max()))
+
+
+def test_fp64_build_of_the_oracle_is_the_same_network():
+    """oracle/liboracle64.so (-DORC_DN_FP64: double activations, products, sums, BatchNorm) is the truth of the drift study
+    (tools/drift_probe.py): one frame of it and of the fp32 build differ by fp32 rounding only, in both BN modes, and its
+    hidden state carries."""
+    blob = synth.make_blob(565)
+    H, W = 64, 96
+    x0, x1 = synth.make_gbuffer(H, W, 3, 0), synth.make_gbuffer(H, W, 3, 1)
+    for bn in (True, False):
+        o32, o64 = DenoiseOracle(blob, H, W), DenoiseOracle(blob, H, W, fp64=True)
+        a, b = o32.forward(x0, bn, False), o64.forward(x0, bn, False)
+        assert np.isfinite(b).all() and 0 < np.abs(a - b).max() < 5e-4
+        a1, b1 = o32.forward(x1, bn, True), o64.forward(x1, bn, True)
+        assert np.abs(a1 - b1).max() < 2e-3
+        assert np.abs(o32.hidden(0) - o64.hidden(0)).max() < 2e-3
+        assert np.abs(o64.forward(x1, bn, False) - b1).max() > 1e-3      # the carried state matters

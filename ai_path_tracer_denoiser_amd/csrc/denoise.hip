@@ -907,7 +907,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 //     pixel, four consecutive channels per register quad: the C4 store is four plain 16-byte stores (no lane transposes), the
 //     2x2 pool is a register max between rows and one lane shift, and the BN sums are a 5-step butterfly per item kept in a
 //     64-bit fixed-point register pair per lane until the workgroup ends (32 x 2 atomics per workgroup, order-independent).
-constexpr int RR_ROWS = 4, RR_PX = 30;
+constexpr int RR_PX = 30;                                     // valid output pixels of an item's row (32 loaded)
 constexpr float XS1 = 16.0f, WS1 = 128.0f;
 constexpr int RR_MAXCH = 8;                                   // chunks whose weights fit LDS (fp16-weight mode: twice as many)
 static inline size_t convr_lds_bytes(int nchunks, bool w16) {
@@ -944,7 +944,9 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
     return a1;
 }
 
-template <bool W16, int NWV, int PF, bool WC>
+// RR_ROWS = output rows of an item: 4 on the levels with many items; 2 on the small levels (twice the items, half the serial
+// chain of steps per item: those launches last as long as one wave's item).
+template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4>
 __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
     static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
@@ -1645,6 +1647,8 @@ static DenoiseState* state(aipt_ctx* ctx) {
             ctx->dn->num_cus = prop.multiProcessorCount;
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1799,18 +1803,23 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
         // the big levels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit LDS
-        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 200000;
+        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 50000;
+        static const long r_minpix4 = getenv("AIPT_F16R_MINPIX4") ? atol(getenv("AIPT_F16R_MINPIX4")) : 200000;   // below: 2-row items
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
         if (!gh.a.planar && (long)H * W >= r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 &&
             !(H & 1) && !(W & 1)) {
             gh.wsplit = L.d_wsplit1;
-            gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + RR_ROWS - 1) / RR_ROWS; gh.groups = r_groups;
+            const int r_rows = (long)H * W >= r_minpix4 ? 4 : 2;
+            gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + r_rows - 1) / r_rows; gh.groups = r_groups;
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
             static const int r_var = getenv("AIPT_F16R_VARIANT") ? atoi(getenv("AIPT_F16R_VARIANT")) : 0;
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s>", w16 ? "true" : "false", r_var == 1 && !w16 ? "8,3,true" : "12,3,false");
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s>", w16 ? "true" : "false",
+                     r_rows == 2 ? "12,4,false,2" : r_var == 1 && !w16 ? "8,3,true,4" : "12,3,false,4");
             {
-            if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            if (r_rows == 2 && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else if (r_rows == 2) hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
             else if (r_var == 1) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
             }

@@ -1803,7 +1803,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
         const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
         // the big levels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit LDS
-        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 50000;
+        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 200000;
         static const long r_minpix4 = getenv("AIPT_F16R_MINPIX4") ? atol(getenv("AIPT_F16R_MINPIX4")) : 200000;   // below: 2-row items
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
         if (!gh.a.planar && (long)H * W >= r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 &&

@@ -20,10 +20,10 @@ pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 python tools/pmc_summarize.py --out $O/pmc_dominant.json $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv \
-    'trace_bounce<false,true,true>' 'trace_bounce<true,true,false>' 'trace_bounce<false,true,false>' 'conv3x3_f16x3<1,8,false,false>' 'conv3x3_f16x3<1,8,true,false>' \
-    'conv3x3_f16x3<1,4,false,false>'
+    'trace_bounce<false,true,true>' 'trace_bounce<true,true,false>' 'trace_bounce<false,true,false>' 'conv3x3_f16x3r<false,12,3,false,4>' \
+    'conv3x3_f16x3<1,8,false,false>' 'conv3x3_f16x3<1,8,true,false>' 'conv3x3_f16x3<1,4,false,false>'
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel trace_bounce --json $O/pmc_trace.json > /dev/null
-python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel 'conv3x3_f16x3<1,8,false,false>' --json $O/pmc_conv.json > /dev/null
+python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel 'conv3x3_f16x3' --json $O/pmc_conv.json > /dev/null
 # the bench lines read roofline.traffic from profiles/pmc_dominant.json: the fresh one
 cp $O/pmc_dominant.json profiles/pmc_dominant.json
 $B > $O/bench_default.json 2> $O/bench_default.err
@@ -38,6 +38,9 @@ $B --no-cpu-baseline --impl f32 --steps 32 > $O/bench_f32exact.json 2>/dev/null
 $B --no-cpu-baseline --trace-flags 35 --batch 1 --steps 30 > $O/bench_sort_material.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -o k -- $B --no-cpu-baseline > $O/kstats.log 2>&1
 AIPT_DN_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_one_stream -o k -- $B --no-cpu-baseline > $O/kstats_one_stream.log 2>&1
+# round 3: what the dominant conv kernel's time is made of (ablation build), VALU beside MFMA on one SIMD, hidden-state drift
+AIPT_F16R_MINPIX=100000000 ABLATE_MASKS="0 1 64 2 4 6 8 16 32 128 7 9 15 17 25 31 63 319 512" tools/conv_ablate.sh run > $O/conv_ablate.txt 2>&1
+[ -x tools/ubench/valu_mfma ] && tools/ubench/valu_mfma > $O/ubench_valu_mfma.txt 2>&1
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # keep the merge small: raw counter CSVs stay on the box
 rm -rf $O/pmc_*/ 

@@ -45,6 +45,11 @@ def main():
         i = args.index("--out")
         outpath = args[i + 1]
         del args[i:i + 2]
+    fpl = None
+    if "--frames-per-launch" in args:                  # frames every batched trace launch of the PMC command held (bench.py
+        i = args.index("--frames-per-launch")          # reports roofline_other.traffic only for runs with the same count)
+        fpl = int(args[i + 1])
+        del args[i:i + 2]
     fcsv, wcsv = args[0:2]
     kernels = args[2:]
     f, w = per_launch(fcsv, "FETCH_SIZE"), per_launch(wcsv, "WRITE_SIZE")
@@ -63,6 +68,8 @@ def main():
         write = 1024.0 * sum(w[k]) / len(w[k])
         out["kernels"][k] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch,
                              "write_bytes_per_launch": write, "launches_averaged": [len(f[k]), len(w[k])]}
+        if fpl and k.startswith("trace_bounce") and k.endswith(",true>"):       # the pooled (batched) instantiation
+            out["kernels"][k]["frames_per_launch"] = fpl
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(outpath or os.path.join(root, "profiles", "pmc_dominant.json"), "w") as fh:
         json.dump(out, fh, indent=1)

@@ -946,7 +946,9 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
 
 // RR_ROWS = output rows of an item: 4 on the levels with many items; 2 on the small levels (twice the items, half the serial
 // chain of steps per item: those launches last as long as one wave's item).
-template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4>
+// PLANAR: source a is the planar network input [C][h][w], C <= 16 (one chunk): eight 4-byte loads per lane and halo row instead of
+// two 16-byte ones, everything after the loads unchanged.
+template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4, bool PLANAR = false>
 __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
     static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
@@ -993,7 +995,7 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         const int rb = item / tiles_x, tx = item - rb * tiles_x;
         pf_y0 = (rb0 + rb) * RR_ROWS;
         const int x = min(max(tx * RR_PX - 1 + m, 0), W - 1);
-        pf_v0 = (unsigned)(up ? (x >> 1) : x) * 16u + (unsigned)(2 * gq) * plane16;
+        pf_v0 = PLANAR ? (unsigned)x * 4u : (unsigned)(up ? (x >> 1) : x) * 16u + (unsigned)(2 * gq) * plane16;
         pf_v1 = pf_v0 + plane16;
     };
     f32x4 raw[PF][2];
@@ -1003,6 +1005,17 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         const bool fa = pf_c < ca16;
         const int cl = fa ? pf_c : pf_c - ca16;
         const ConvSrc& sr = fa ? g.a : g.b;
+        if (PLANAR) {
+            // channel 8 gq + t of this lane's pixel (past the last channel: the last one again; its BN coefficients are (0, 0))
+            const unsigned planeb = plane16 >> 2;                                  // bytes of one channel plane
+            const unsigned char* rowp = reinterpret_cast<const unsigned char*>(g.a.p) + (roff >> 2);
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const unsigned c0 = (unsigned)min(t, g.a.C - 1) * planeb, c1 = (unsigned)min(8 + t, g.a.C - 1) * planeb;
+                raw[slot][t >> 2][t & 3] = *reinterpret_cast<const float*>(rowp + (pf_v0 + (gq ? c1 : c0)));
+            }
+            return;
+        }
         // (tensors are allocated in whole 16-channel chunks: no clamping of pad quads; scalar row base + per-lane offset)
         const unsigned char* rowp = reinterpret_cast<const unsigned char*>(sr.p) + ((size_t)cl * 4 * plane16 + roff);
         raw[slot][0] = *reinterpret_cast<const f32x4*>(rowp + pf_v0);
@@ -1559,7 +1572,7 @@ struct DenoiseState {
     int prof_max = 0, prof_calls = 0;
     int prof_every = 1, prof_seen = 0;   // sample every prof_every-th forward (aipt_denoise_profile_stride)
     std::vector<hipEvent_t> prof_ev;     // [call][layer][2]
-    char kname[NLAYERS][40] = {};        // kernel that ran each layer in the last forward
+    char kname[NLAYERS][56] = {};        // kernel that ran each layer in the last forward
 };
 
 // smallest level (in pixels) that runs on the split-fp16 kernel; below it the f32-MFMA kernels with their smaller tiles
@@ -1647,6 +1660,8 @@ static DenoiseState* state(aipt_ctx* ctx) {
             ctx->dn->num_cus = prop.multiProcessorCount;
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1806,16 +1821,20 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 200000;
         static const long r_minpix4 = getenv("AIPT_F16R_MINPIX4") ? atol(getenv("AIPT_F16R_MINPIX4")) : 200000;   // below: 2-row items
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
-        if (!gh.a.planar && (long)H * W >= r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 &&
-            !(H & 1) && !(W & 1)) {
+        static const int r_planar = getenv("AIPT_F16R_PLANAR") ? atoi(getenv("AIPT_F16R_PLANAR")) : 1;
+        if ((!gh.a.planar || (r_planar && gh.nchunks == 1 && !gh.b.C && !gh.a.up && gh.a.C <= 16)) && (long)H * W >= r_minpix &&
+            gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 && !(H & 1) && !(W & 1)) {
             gh.wsplit = L.d_wsplit1;
             const int r_rows = (long)H * W >= r_minpix4 ? 4 : 2;
             gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + r_rows - 1) / r_rows; gh.groups = r_groups;
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
             static const int r_var = getenv("AIPT_F16R_VARIANT") ? atoi(getenv("AIPT_F16R_VARIANT")) : 0;
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s>", w16 ? "true" : "false",
-                     r_rows == 2 ? "12,4,false,2" : r_var == 1 && !w16 ? "8,3,true,4" : "12,3,false,4");
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s,%s>", w16 ? "true" : "false",
+                     r_rows == 2 ? "12,4,false,2" : gh.a.planar ? "8,3,false,4" : r_var == 1 && !w16 ? "8,3,true,4" : "12,3,false,4", gh.a.planar ? "true" : "false");
+            if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            else
             {
             if (r_rows == 2 && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);
             else if (r_rows == 2) hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);

@@ -15,8 +15,9 @@
 // MaxPool needs normalised values, so one small pool kernel per encoder level materialises the pooled, normalised skip
 // tensor (quarter size).
 //
-// Kernels: conv3x3_f16x3 -- implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into fp16 hi/lo pairs (the
-// default on levels >= 92 x 160, the depth-to-space form of dec1.c1 and the planar-input first conv included);
+// Kernels: conv3x3_f16x3r -- the two big levels (>= 368 x 640, the planar-input first conv included): persistent, register-staged
+// implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into fp16 hi/lo pairs, weights resident in LDS, no barriers;
+// conv3x3_f16x3 -- the same arithmetic LDS-tiled and barrier-phased (the levels below, and the depth-to-space form of dec1.c1);
 // conv3x3_mfma -- the same GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation; the deep levels, and
 // everything under AIPT_DN_IMPL_MFMA); conv3x3_quad -- the 3 -> 3 output layer.  Rooflines and measurements: DESIGN.md.
 #include "internal.h"

@@ -28,6 +28,7 @@ SCENE_RECOMPUTE_NORMALS = 1
 TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
 DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
 DN_IMPL_MFMA, DN_IMPL_VALU, DN_IMPL_MFMA_F16X3, DN_IMPL_MFMA_F16W = 0, 1, 2, 3
+DN_OPT_R_MINPIX, DN_OPT_F16_MINPIX, DN_OPT_SMALL_MINPIX, DN_OPT_FUSED_POOL = 1, 2, 3, 4
 GEOM_SPHERE, GEOM_CUBE = 0, 1
 
 
@@ -100,6 +101,7 @@ ABI = [
     ("aipt_denoise_load_weights", C.c_int, [_P, _P, C.c_size_t]),
     ("aipt_denoise_configure", C.c_int, [_P, C.c_int, C.c_int]),
     ("aipt_denoise_set_impl", C.c_int, [_P, C.c_int]),
+    ("aipt_denoise_set_option", C.c_int, [_P, C.c_int, C.c_longlong]),
     ("aipt_denoise", C.c_int, [_P, _P, _P, C.c_uint32]),
     ("aipt_denoise_reset_hidden", C.c_int, [_P]),
     ("aipt_denoise_get_hidden", C.c_int, [_P, C.c_int, _P]),
@@ -375,6 +377,10 @@ class Context:
 
     def denoise_set_impl(self, impl: int):
         self._ck(lib().aipt_denoise_set_impl(self._h, impl))
+
+    def denoise_set_option(self, option, value):
+        """aipt_denoise_set_option: DN_OPT_R_MINPIX / DN_OPT_F16_MINPIX / DN_OPT_SMALL_MINPIX / DN_OPT_FUSED_POOL"""
+        self._ck(lib().aipt_denoise_set_option(self._h, option, value))
 
     def denoise(self, x10, out3, bn_batch: bool = True, carry: bool = False):
         """module.forward: x10 [10,H,W] -> out3 [3,H,W], float32 contiguous device tensors."""

@@ -32,7 +32,6 @@ constexpr int KC = 8;            // input channels per LDS chunk (2 MFMA k-steps
 constexpr int NLAYERS = 28;
 constexpr float BN_EPS = 1e-5f;
 constexpr float SLOPE = 0.1f;
-constexpr int AIPT_DN_IMPL_MFMA_NOFEW = 99;   // (internal) disable the few-output kernel
 
 static const int ENC_CH[5] = {32, 43, 57, 76, 101};
 static const int DEC_CH[6] = {0, 3, 32, 43, 57, 76};
@@ -47,22 +46,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // producing conv left per-channel sums in `stat` (64-bit atomics into NSLOT replicas, slot = workgroup % NSLOT: 3680
 // workgroups x 64 atomics cost 1.6 us that way, tools/atomicbench.hip) and every consumer workgroup turns them into
 // (a, b) itself in its prologue -- there is no finalize launch between two convs (28 launches x 4.1 us per frame).
-// The sums are 64-bit FIXED-POINT integers (24 fractional bits for sums, 20 for sums of squares, see BN_FIX2;
-// raw conv outputs of a BatchNorm network are O(10)): integer addition is associative, so the statistics -- and with them
-// every output bit -- do not depend on the order in which the workgroups' atomics land.  (fp64 sums of fp32 partials are
-// exact only while all partials fit one 53-bit window; a channel with a wide spread of partial magnitudes broke
-// run-to-run equality about once in 15 runs.)  A partial is rounded to 2^-24 once (6e-8 absolute on a workgroup's sum
-// over >= 128 pixels), far below BatchNorm's eps.  The table stays addressed as doubles (8-byte slots).
+// The sums are FIXED-POINT integers, two 64-bit words per sum (integer part + 40 fractional bits): integer addition is
+// associative, so the statistics -- and with them every output bit -- do not depend on the order in which the workgroups'
+// atomics land.  (fp64 sums of fp32 partials are exact only while all partials fit one 53-bit window; a channel with a wide
+// spread of partial magnitudes broke run-to-run equality about once in 15 runs.)  Range: |sum| < 9.2e18, whatever the scale
+// of the tensor (rounds 2-3 kept ONE word with 24 / 20 fractional bits: a sum of squares past 8.8e12 -- an rms of 3 000 at
+// 720p, which a G-buffer in centimetres reaches after the first conv -- wrapped silently).  A partial is rounded to 2^-40 once.
 // Running statistics / identity: `ab` (or nothing).
 constexpr int NSLOT = 8;
-constexpr double BN_FIX = 16777216.0, BN_FIX_INV = 1.0 / 16777216.0;       // 2^24: sums, |sum| < 2^39 = 5.5e11
-// Sums of SQUARES keep 20 fractional bits: < 2^43 = 8.8e12, a root mean square of 3 000 at 1280 x 736 (with 24 bits the sum
-// wrapped silently at an rms of ~740, which HDR inputs can reach).  A partial is rounded to 2^-20 once: at most 1e-6 on a
-// workgroup's sum over >= 128 pixels, i.e. < 1e-8 per pixel against BatchNorm's eps of 1e-5.
-constexpr double BN_FIX2 = 1048576.0, BN_FIX2_INV = 1.0 / 1048576.0;
+constexpr int BN_WORDS = 4;                                   // per channel: {sum: integer part, fraction * 2^40, sum of squares: the same}
+constexpr double BN_FRAC = 1099511627776.0, BN_FRAC_INV = 1.0 / 1099511627776.0;   // 2^40
 struct BnRef {
     const float2* ab;      // explicit affine; with stat == nullptr and ab == nullptr: identity
-    const double* stat;    // [NSLOT][sc][2]: sum, sum of squares
+    const long long* stat; // [NSLOT][sc][BN_WORDS]
     const float* gamma;
     const float* beta;
     int sc;                // channel stride of stat
@@ -73,14 +69,17 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
         // all replicas are loaded before the first add: written as one accumulate loop, hipcc waits for each 16-byte load
         // before issuing the next (8 serial L2 round trips, 7 k cycles per consumer workgroup)
         typedef long long l2 __attribute__((ext_vector_type(2)));
-        const l2* st = reinterpret_cast<const l2*>(r.stat) + c;
-        l2 v[NSLOT];
+        const l2* st = reinterpret_cast<const l2*>(r.stat) + (size_t)c * 2;
+        l2 v[NSLOT][2];
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) v[k] = __builtin_nontemporal_load(st + (size_t)k * r.sc);
-        long long ix = 0, ixx = 0;
+        for (int k = 0; k < NSLOT; k++) {
+            v[k][0] = __builtin_nontemporal_load(st + (size_t)k * r.sc * 2);
+            v[k][1] = __builtin_nontemporal_load(st + (size_t)k * r.sc * 2 + 1);
+        }
+        long long xi = 0, xf = 0, qi = 0, qf = 0;
 #pragma unroll
-        for (int k = 0; k < NSLOT; k++) { ix += v[k][0]; ixx += v[k][1]; }
-        const double sx = (double)ix * BN_FIX_INV, sxx = (double)ixx * BN_FIX2_INV;
+        for (int k = 0; k < NSLOT; k++) { xi += v[k][0][0]; xf += v[k][0][1]; qi += v[k][1][0]; qf += v[k][1][1]; }
+        const double sx = (double)xi + (double)xf * BN_FRAC_INV, sxx = (double)qi + (double)qf * BN_FRAC_INV;
         const double mean = sx * r.inv_n;
         double var = sxx * r.inv_n - mean * mean;          // biased variance, as torch normalises with
         if (var < 0) var = 0;
@@ -90,17 +89,27 @@ __device__ __forceinline__ float2 bn_ab(const BnRef& r, int c) {
     }
     return r.ab ? r.ab[c] : make_float2(1.0f, 0.0f);
 }
+// a (workgroup's) sum -> its two fixed-point words; clamped so that NaN / inf stay defined
+struct BnFix { long long i, f; };
+__device__ __forceinline__ BnFix bn_fix(double v) {
+    v = fmin(fmax(v, -9.0e18), 9.0e18);
+    if (!(v == v)) v = 0.0;
+    const double fl = floor(v);
+    BnFix r;
+    r.i = __double2ll_rn(fl);
+    r.f = __double2ll_rn((v - fl) * BN_FRAC);              // [0, 2^40]
+    return r;
+}
 // a workgroup's BN sums of channel c (already reduced over the workgroup) -> the producer's stat table
-__device__ __forceinline__ long long bn_fix(double v, double scale = BN_FIX) {      // fixed point; clamped so that NaN / inf stay defined
-    v = fmin(fmax(v * scale, -4.0e18), 4.0e18);
-    return v == v ? __double2ll_rn(v) : 0ll;
+__device__ __forceinline__ void bn_accumulate_slot(long long* stat, int sc, int slot, int c, double sum, double sumsq) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(stat + ((size_t)slot * sc + c) * BN_WORDS);
+    const BnFix x = bn_fix(sum), q = bn_fix(sumsq);
+    atomicAdd(a, (unsigned long long)x.i);
+    atomicAdd(a + 1, (unsigned long long)x.f);
+    atomicAdd(a + 2, (unsigned long long)q.i);
+    atomicAdd(a + 3, (unsigned long long)q.f);
 }
-__device__ __forceinline__ void bn_accumulate_slot(double* stat, int sc, int slot, int c, double sum, double sumsq) {
-    unsigned long long* a = reinterpret_cast<unsigned long long*>(stat + ((size_t)slot * sc + c) * 2);
-    atomicAdd(a, (unsigned long long)bn_fix(sum));
-    atomicAdd(a + 1, (unsigned long long)bn_fix(sumsq, BN_FIX2));
-}
-__device__ __forceinline__ void bn_accumulate(double* stat, int sc, int c, float sum, float sumsq) {
+__device__ __forceinline__ void bn_accumulate(long long* stat, int sc, int c, float sum, float sumsq) {
     bn_accumulate_slot(stat, sc, blockIdx.x % NSLOT, c, (double)sum, (double)sumsq);
 }
 
@@ -125,7 +134,7 @@ struct ConvArgs {
     int cin, cout, NP, nchunks;
     float* out;          // [cout][H][W] raw
     int out_lrelu;
-    double* stat;        // BN sums of the output (nullptr: not wanted), [NSLOT][sc][2]
+    long long* stat;     // BN sums of the output (nullptr: not wanted), [NSLOT][sc][BN_WORDS]
     int sc;
     int d2s;             // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to out[j][2y+a][2x+b]
     int tiles_x, tiles_y, groups;   // pixel tiles and output-channel groups of the launch (1-D XCD-aware grid)
@@ -453,14 +462,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// -DAIPT_ONE_ACC (experiment): both halves of the split accumulate into ONE fp32 accumulator.  Activations are staged times
-// 2^4 and weights stored times 2^7, their low halves unscaled relative to those (normal fp16 numbers for |x| >= 2^-7,
-// |w| >= 2^-10; smaller ones lose bits below 2^-25 of the unscaled value), the result is scaled back by 2^-11.
-#ifdef AIPT_ONE_ACC
-constexpr float XS = 16.0f, WS = 128.0f, LO_SCALE = 1.0f;
-#else
-constexpr float XS = 1.0f, WS = 1.0f, LO_SCALE = 2048.0f;
-#endif
+// Two accumulators: acc0 takes hi * hi, acc1 the two cross terms with the low halves scaled by 2^11 (normal fp16 numbers down to
+// |x| = 2^-25: no absolute floor that matters); result = acc0 + acc1 * 2^-11.
+// PLANAR network input (identity transform, unknown units -- HDR radiance, first-hit distance in scene units): staged times
+// XSP = 2^-4 and scaled back in the epilogue, so that the operand split holds |x| up to 2^20 (1.0e6) instead of 65 504.
+constexpr float LO_SCALE = 2048.0f;
+constexpr float XSP = 0.0625f;
 constexpr int KH = 16;             // input channels per chunk of the fp16 kernel
 constexpr int PXB = 48;            // bytes per pixel / per weight row in LDS (16 halfs + 8 halfs padding)
 constexpr int WSLAB = 2 * 9 * 32 * KH * 2;   // bytes of one (group, chunk) weight slab: hi and lo
@@ -477,7 +484,7 @@ struct ConvArgsH {
     int wchunks;                   // chunks per group in wsplit
     float* out;
     int out_lrelu;
-    double* stat;                  // BN sums of the output (nullptr: not wanted), [NSLOT][sc][2]
+    long long* stat;               // BN sums of the output (nullptr: not wanted), [NSLOT][sc][BN_WORDS]
     int sc;
     int d2s;                       // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to pixel (2y+a, 2x+b), channel j
     int tiles_x, tiles_y, groups;
@@ -609,19 +616,11 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const unsigned char* wslab = g.wsplit + (size_t)tile.gz * g.wchunks * WSLAB + tid * 16;
 
     const float bj = g.bias[n0 + li];
-#ifdef AIPT_ONE_ACC
-    f32x16 acc0[RW];
-#pragma unroll
-    for (int r = 0; r < RW; r++)
-#pragma unroll
-        for (int k = 0; k < 16; k++) acc0[r][k] = 0.f;
-#else
     f32x16 acc0[RW], acc1[RW];
 #pragma unroll
     for (int r = 0; r < RW; r++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) { acc0[r][k] = bj; acc1[r][k] = 0.f; }
-#endif
+        for (int k = 0; k < 16; k++) { acc0[r][k] = PLANAR ? bj * XSP : bj; acc1[r][k] = 0.f; }
 
     f32x4 pa[NU];
     u32x4 pw[NWP];
@@ -705,8 +704,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         const ConvSrc& s = fa ? g.a : g.b;
         float2 t = make_float2(0.0f, 0.0f);
         if (c < s.C && !(abl & 256)) t = bn_ab(s.bn, c);
-        tab_a[kc] = t.x * XS;                                  // (LeakyReLU is positively homogeneous: the scale commutes)
-        tab_b[kc] = t.y * XS;
+        tab_a[kc] = PLANAR ? t.x * XSP : t.x;                  // (LeakyReLU is positively homogeneous: the scale commutes)
+        tab_b[kc] = PLANAR ? t.y * XSP : t.y;
     }
     CPH(11);
     // zeroed halo image: only tiles whose halo leaves the image need it (out-of-image units never write); an interior tile
@@ -750,15 +749,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #endif
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
-#ifdef AIPT_ONE_ACC
-                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
-                    if (!W16) acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc0[r], 0, 0, 0);
-                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc0[r], 0, 0, 0);
-#else
                     acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
                     if (!W16) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
                     acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc1[r], 0, 0, 0);
-#endif
                 }
             }
         }
@@ -778,11 +771,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         const int y = ty0 + wave * RW + r;
-#ifdef AIPT_ONE_ACC
-        f32x16 t = acc0[r] * (1.0f / (XS * WS)) + bj;
-#else
         f32x16 t = acc0[r] + acc1[r] * (1.0f / 2048.0f);
-#endif
+        if (PLANAR) t = t * (1.0f / XSP);
         if (g.out_lrelu) {
 #pragma unroll
             for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
@@ -912,7 +902,7 @@ constexpr int RR_PX = 30;                                     // valid output pi
 constexpr float XS1 = 16.0f, WS1 = 128.0f;
 constexpr int RR_MAXCH = 8;                                   // chunks whose weights fit LDS (fp16-weight mode: twice as many)
 static inline size_t convr_lds_bytes(int nchunks, bool w16) {
-    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * 2 * 8 + 32;
+    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * BN_WORDS * 8 + 32;
 }
 
 // lo half of the split: the fp16 roundings of v0 - hi.lo and v1 - hi.hi, packed, in two mixed-precision FMAs (instead of two
@@ -921,6 +911,14 @@ __device__ __forceinline__ unsigned split_lo_mix(unsigned hi, float v0, float v1
     unsigned d;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(v0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(v1));
+    return d;
+}
+// the same for the two-accumulator arithmetic of the planar input: the fp16 roundings of (v - hi) * 2^11, from vs = v * 2^11 and
+// nscale = -2^11 (exact in fp32: hi is v rounded toward zero to 11 bits, the remainder has at most 13)
+__device__ __forceinline__ unsigned split_lo_mix_scaled(unsigned hi, float v0s, float v1s, float nscale) {
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(v0s), "v"(nscale));
+    asm("v_fma_mixhi_f16 %0, %1, %3, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hi), "v"(v1s), "v"(nscale));
     return d;
 }
 __device__ __forceinline__ unsigned dpp_wave_shr1(unsigned v) {   // lane i <- lane i - 1
@@ -948,7 +946,11 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
 // RR_ROWS = output rows of an item: 4 on the levels with many items; 2 on the small levels (twice the items, half the serial
 // chain of steps per item: those launches last as long as one wave's item).
 // PLANAR: source a is the planar network input [C][h][w], C <= 16 (one chunk): eight 4-byte loads per lane and halo row instead of
-// two 16-byte ones, everything after the loads unchanged.
+// two 16-byte ones.  Its values are in the caller's units (identity transform, no LeakyReLU), so this instantiation keeps the
+// wide-range arithmetic of conv3x3_f16x3: input times XSP = 2^-4, TWO accumulators, low halves scaled by 2^11, weights from the
+// hi + 2^11 lo slabs -- |x| up to 1.0e6 and no absolute floor (the single-accumulator form holds |x| < 4 094 and loses bits
+// below 2^-29, fine for normalised activations, not for a first-hit distance in centimetres).  One chunk: the layer is bound by
+// its 158 MB, the second accumulator is free (8 waves per CU).
 template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4, bool PLANAR = false>
 __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
@@ -960,8 +962,8 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
     float* bias_s = tab_b + nch * KH;                          // [32], times 2^11: the accumulators start from it
-    long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][2]
-    const float* zeros = reinterpret_cast<const float*>(bnacc + 64);  // [8]: the BN coefficients of out-of-image pixels
+    long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][BN_WORDS]
+    const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [8]: the BN coefficients of out-of-image pixels
 
     // ---- workgroup -> (XCD, output-channel group); XCD b & 7 owns a contiguous band of item rows
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
@@ -1043,11 +1045,11 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
             const ConvSrc& sr = fa ? g.a : g.b;
             float2 t = make_float2(0.0f, 0.0f);
             if (c < sr.C) t = bn_ab(sr.bn, c);
-            tab_a[kc] = t.x * XS1;
-            tab_b[kc] = t.y * XS1;
+            tab_a[kc] = t.x * (PLANAR ? XSP : XS1);
+            tab_b[kc] = t.y * (PLANAR ? XSP : XS1);
         }
-        if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (XS1 * WS1);
-        if (tid < 64) bnacc[tid] = 0;
+        if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (PLANAR ? XSP : XS1 * WS1);
+        if (tid < 32 * BN_WORDS) bnacc[tid] = 0;
         if (tid < 8) const_cast<float*>(zeros)[tid] = 0.0f;
     }
     __syncthreads();
@@ -1058,7 +1060,13 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
         const int x = X + m;
         const bool xin = x >= 0 && x < W;
-        f32x16 acc[RR_ROWS];
+        f32x16 acc[RR_ROWS], acc1[PLANAR ? RR_ROWS : 1];
+        if (PLANAR) {
+#pragma unroll
+            for (int r = 0; r < RR_ROWS; r++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc1[r][k] = 0.f;
+        }
         {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -1106,9 +1114,9 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
                     const f32x4& bb = (p >> 1) ? b1 : b0;
                     const int e = (p & 1) * 2;
                     float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
-                    v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope);
+                    if (!PLANAR) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }   // (the network input has no LeakyReLU: the host checks)
                     xh[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-                    xl[p] = split_lo_mix(xh[p], v0, v1);
+                    xl[p] = PLANAR ? split_lo_mix_scaled(xh[p], v0 * LO_SCALE, v1 * LO_SCALE, -LO_SCALE) : split_lo_mix(xh[p], v0, v1);
                     if (WC) { xh[p] = ok ? xh[p] : 0u; xl[p] = ok ? xl[p] : 0u; }
                 }
                 // ---- the ring slot is free: fetch PF rows ahead (into the next chunk / the next item when that wraps)
@@ -1136,12 +1144,13 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
                         const int r = h - ky;
                         if (r < 0 || r >= RR_ROWS) continue;
                         const f16x8 fwh = WC ? wfh[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
+                        f32x16& lo_acc = PLANAR ? acc1[PLANAR ? r : 0] : acc[r];
                         acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, acc[r], 0, 0, 0);
                         if (!W16) {
                             const f16x8 fwl = WC ? wfl[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
-                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, acc[r], 0, 0, 0);
+                            lo_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, lo_acc, 0, 0, 0);
                         }
-                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, acc[r], 0, 0, 0);
+                        lo_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, lo_acc, 0, 0, 0);
                     }
                 }
             }
@@ -1155,7 +1164,8 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         for (int k = 0; k < 16; k++) { s1[k] = 0.f; s2[k] = 0.f; }
 #pragma unroll
         for (int r = 0; r < RR_ROWS; r++) {
-            acc[r] = acc[r] * (1.0f / (XS1 * WS1));
+            if (PLANAR) acc[r] = (acc[r] + acc1[PLANAR ? r : 0] * (1.0f / LO_SCALE)) * (1.0f / XSP);
+            else acc[r] = acc[r] * (1.0f / (XS1 * WS1));
             if (g.out_lrelu) {
 #pragma unroll
                 for (int k = 0; k < 16; k++) acc[r][k] = fmaxf(acc[r][k], acc[r][k] * SLOPE);
@@ -1211,105 +1221,16 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
         if (m < 16) {
             const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
             const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2), (unsigned long long)bn_fix((double)bsum1));
-            atomicAdd(reinterpret_cast<unsigned long long*>(bnacc + cl * 2 + 1), (unsigned long long)bn_fix((double)bsum2, BN_FIX2));
+            const BnFix fx = bn_fix((double)bsum1), fq = bn_fix((double)bsum2);
+            unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
+            atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
+            atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
         }
         __syncthreads();
         if (tid < 32 && n0 + tid < g.cout) {
-            unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * 2);
-            atomicAdd(dst, (unsigned long long)bnacc[tid * 2]);
-            atomicAdd(dst + 1, (unsigned long long)bnacc[tid * 2 + 1]);
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------- few-output conv
-// dec1.c1 (64 -> 3) and dec1.c2 (3 -> 3) have too few output channels for an MFMA N dimension (3 of 16/32 columns used).
-// Direct conv on the VALU instead: one thread per output pixel, COUT accumulators, input halo tile in LDS (already
-// normalised), weights read through the scalar cache (their index is wave-uniform).  Tile = 16 x 16 pixels, 16 input
-// channels per LDS chunk; for upsampled sources the LDS tile is the half-resolution 10 x 10 patch.
-template <int COUT>
-__global__ __launch_bounds__(256) void conv3x3_fewout(const ConvArgs g) {
-    constexpr int TS = 16, CK = 16;
-    __shared__ float tile[CK * 18 * 18];
-    __shared__ float2 red[4][COUT];
-    __shared__ float2 abt[224];                                     // (a, b) of every input channel (concat order)
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-    const int tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS;
-    const int H = g.H, W = g.W;
-    const int up = g.a.up;
-    const int sh = up ? (H >> 1) : H, sw = up ? (W >> 1) : W;
-    // source-resolution patch covering the tile's 18 x 18 halo
-    const int py0 = up ? ((ty0 - 1) >> 1) : ty0 - 1, px0 = up ? ((tx0 - 1) >> 1) : tx0 - 1;   // arithmetic shift: -1 -> -1
-    const int PH = up ? 10 : 18, PW = up ? 10 : 18;
-    const int aC = g.a.C, ctot = g.a.C + g.b.C;
-    for (int c = tid; c < ctot; c += 256) abt[c] = c < aC ? bn_ab(g.a.bn, c) : bn_ab(g.b.bn, c - aC);
-    float acc[COUT];
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * BN_WORDS);
 #pragma unroll
-    for (int j = 0; j < COUT; j++) acc[j] = 0.f;
-    const int x = tx0 + lx, y = ty0 + ly;
-    for (int c0 = 0; c0 < ctot; c0 += CK) {
-        __syncthreads();
-        for (int e = tid; e < CK * PH * PW; e += 256) {
-            const int c = e / (PH * PW), rem = e - c * (PH * PW);
-            const int yy = rem / PW, xx = rem - yy * PW;
-            const int sy = py0 + yy, sx = px0 + xx, cg = c0 + c;
-            float v = 0.f;
-            if (cg < ctot && sy >= 0 && sy < sh && sx >= 0 && sx < sw) {
-                const ConvSrc& src = cg < aC ? g.a : g.b;
-                const int ch = cg < aC ? cg : cg - aC;
-                v = src.planar ? src.p[((size_t)ch * sh + sy) * sw + sx]
-                               : src.p[(((size_t)(ch >> 2) * sh + sy) * sw + sx) * 4 + (ch & 3)];
-                { const float2 ab = abt[cg]; v = fmaf(ab.x, v, ab.y); }
-                v = lrelu(v, src.slope);
-            }
-            tile[e] = v;
-        }
-        __syncthreads();
-        const int cn = ctot - c0 < CK ? ctot - c0 : CK;
-        for (int c = 0; c < cn; c++) {
-            const float* wk = g.w_raw + (size_t)(c0 + c) * 9;      // + j*cin*9 per output channel; wave-uniform
-            const float* tp = tile + c * (PH * PW);
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
-                const int yy = y + ky - 1;
-                const int ry = (up ? (yy >> 1) : yy) - py0;
-                const bool yin = yy >= 0 && yy < H;
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const int xx = x + kx - 1;
-                    const int rx = (up ? (xx >> 1) : xx) - px0;
-                    // out-of-image taps are zero in the NORMALISED domain (the patch already holds 0 there for the
-                    // source-resolution border; at full resolution an odd border pixel maps inside the patch)
-                    const float v = (yin && xx >= 0 && xx < W) ? tp[ry * PW + rx] : 0.f;
-#pragma unroll
-                    for (int j = 0; j < COUT; j++) acc[j] = fmaf(v, wk[(size_t)j * g.cin * 9 + ky * 3 + kx], acc[j]);
-                }
-            }
-        }
-    }
-    float s1[COUT], s2[COUT];
-    const bool ok = x < W && y < H;
-#pragma unroll
-    for (int j = 0; j < COUT; j++) {
-        float t = acc[j] + g.bias[j];
-        if (g.out_lrelu) t = lrelu(t, SLOPE);
-        if (ok && j < g.cout) g.out[(((size_t)(j >> 2) * H + y) * W + x) * 4 + (j & 3)] = t;
-        s1[j] = ok ? t : 0.f; s2[j] = ok ? t * t : 0.f;
-    }
-    if (g.stat) {
-        const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int j = 0; j < COUT; j++) {
-            float a = s1[j], b = s2[j];
-            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-            if (lane == 0) red[wave][j] = make_float2(a, b);
-        }
-        __syncthreads();
-        if (tid < COUT && tid < g.cout) {
-            float2 t = red[0][tid];
-            for (int w = 1; w < 4; w++) { t.x += red[w][tid].x; t.y += red[w][tid].y; }
-            bn_accumulate_slot(g.stat, g.sc, (blockIdx.y * gridDim.x + blockIdx.x) % NSLOT, tid, (double)t.x, (double)t.y);
+            for (int k = 0; k < BN_WORDS; k++) atomicAdd(dst + k, (unsigned long long)bnacc[tid * BN_WORDS + k]);
         }
     }
 }
@@ -1426,7 +1347,7 @@ __global__ __launch_bounds__(64) void conv3x3_valu(const ConvArgs g) {
 }
 
 // per-channel sum / sum-of-squares of a stored tensor (VALU path only): one block per channel
-__global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, double* stat) {
+__global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, long long* stat) {
     const int c = blockIdx.x;
     const float* p = t + (size_t)(c >> 2) * hw * 4 + (c & 3);      // C4 layout
     double a = 0, b = 0;
@@ -1439,8 +1360,9 @@ __global__ __launch_bounds__(256) void channel_stats(const float* t, size_t hw, 
         __syncthreads();
     }
     if (threadIdx.x == 0) {                                    // slot 0 of a zeroed table, in the table's fixed-point format
-        reinterpret_cast<long long*>(stat)[blockIdx.x * 2] = bn_fix(sa[0]);
-        reinterpret_cast<long long*>(stat)[blockIdx.x * 2 + 1] = bn_fix(sb[0], BN_FIX2);
+        const BnFix fx = bn_fix(sa[0]), fq = bn_fix(sb[0]);
+        long long* d = stat + (size_t)blockIdx.x * BN_WORDS;
+        d[0] = fx.i; d[1] = fx.f; d[2] = fq.i; d[3] = fq.f;
     }
 }
 
@@ -1521,6 +1443,7 @@ struct LayerW {
     int coutp32 = 0, nchunks16 = 0, ca16 = 0;
     unsigned char* d_wsplit = nullptr;
     unsigned char* d_wsplit1 = nullptr;      // the same tiling in the single-accumulator scaling of conv3x3_f16x3r: hi = fp16(2^7 w), lo unscaled
+    unsigned char* d_wsplit1_16 = nullptr;   // ... of the fp16-ROUNDED weights (AIPT_DN_IMPL_MFMA_F16W): hi = 2^7 fp16(w) exactly, lo = 0
     float* d_bias32 = nullptr;
     unsigned char* d_wsplit_d2s = nullptr;   // the same layout for the depth-to-space form of dec1.c1 (12 virtual outputs in one group)
     float* d_bias32_d2s = nullptr;
@@ -1553,9 +1476,9 @@ struct DenoiseState {
     // zeroed for frame n belonged to frame n - 2 NSET (same stream: retired) and was last read, as hidden-state statistics,
     // by frame n - 2 NSET + 1, whose bottleneck the frames in between have waited for.
     static constexpr int STAT_SC = 128;                                    // channel stride (>= every cout)
-    static constexpr size_t STAT_LAYER = (size_t)NSLOT * STAT_SC * 2;      // doubles per layer
+    static constexpr size_t STAT_LAYER = (size_t)NSLOT * STAT_SC * BN_WORDS;   // 64-bit words per layer
     static constexpr int STAT_SETS = 2 * AIPT_DN_PIPE;
-    double* stat[STAT_SETS] = {};
+    long long* stat[STAT_SETS] = {};
     int sset = 0;
     // Frame pipelining (aipt_frames): frame n+1 may enter encoder level L as soon as frame n has left it (its hidden state of
     // that level is complete), so the launches of NSET frames interleave on NSET streams and the many small launches of the
@@ -1567,6 +1490,14 @@ struct DenoiseState {
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
     int num_cus = 256;
+    // kernel selection of the split-fp16 implementations (aipt_denoise_set_option; level sizes in pixels)
+    long long opt_r_minpix = 200000;   // >= : conv3x3_f16x3r (register-staged, persistent)
+    long long opt_f16_minpix = 14000;  // >= : conv3x3_f16x3 with 8-row tiles, below: 4-row tiles
+    long long opt_small_minpix = 0;    // <  : the f32-MFMA kernels
+    int opt_fused_pool = 1;            // 2x2 pool of an encoder block's output in the conv's epilogue (0: pool2_norm launches)
+    // largest |gamma| / |beta| of the loaded BatchNorms: with batch statistics |BN(x)| <= |gamma| sqrt(pixels) + |beta|, which
+    // decides whether a level may run on kernels that hold normalised activations in fp16 pairs (run_conv)
+    float bn_gmax = 0.0f, bn_bmax = 0.0f;
     std::vector<void*> allocs;
     // per-layer HIP-event profiling (aipt_denoise_profile_*)
     uint32_t prof_mask = 0;
@@ -1576,19 +1507,8 @@ struct DenoiseState {
     char kname[NLAYERS][56] = {};        // kernel that ran each layer in the last forward
 };
 
-// smallest level (in pixels) that runs on the split-fp16 kernel; below it the f32-MFMA kernels with their smaller tiles
-// fill the chip better (AIPT_F16_MINPIX overrides, for tuning)
-// smallest level that runs on the split-fp16 kernel at all (with 2- or 4-row tiles below f16_min_pixels)
-static long f16_small_min_pixels() {
-    static const long v = getenv("AIPT_F16_SMALL_MINPIX") ? atol(getenv("AIPT_F16_SMALL_MINPIX")) : 0;
-    return v;
-}
 static inline bool w16_mode(const DenoiseState* s) { return s->impl == AIPT_DN_IMPL_MFMA_F16W; }
 static inline bool impl_is_f16(int impl) { return impl == AIPT_DN_IMPL_MFMA_F16X3 || impl == AIPT_DN_IMPL_MFMA_F16W; }
-static long f16_min_pixels() {
-    static const long v = getenv("AIPT_F16_MINPIX") ? atol(getenv("AIPT_F16_MINPIX")) : 14000;
-    return v;
-}
 
 static void build_table(int* cin, int* cout) {
     int n = 0, c_in = 10;
@@ -1614,7 +1534,7 @@ static void free_weights(DenoiseState* s) {
     for (auto& l : s->L) {
         hipFree(l.d_w_raw16); hipFree(l.d_wsplit_d2s16);
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
-        hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_wsplit1); hipFree(l.d_bias32);
+        hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_wsplit1); hipFree(l.d_wsplit1_16); hipFree(l.d_bias32);
         hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s); hipFree(l.d_wsplit_d2s); hipFree(l.d_bias32_d2s);
         l = LayerW();
     }
@@ -1659,14 +1579,17 @@ static DenoiseState* state(aipt_ctx* ctx) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
             ctx->dn->num_cus = prop.multiProcessorCount;
+#if defined(AIPT_DEBUG_HOOKS) || defined(AIPT_CONV_ABLATE)
+        // debug / ablation builds only (tools/conv_ablate.sh): initial values of the selection options from the environment
+        if (getenv("AIPT_F16R_MINPIX")) ctx->dn->opt_r_minpix = atoll(getenv("AIPT_F16R_MINPIX"));
+        if (getenv("AIPT_F16_MINPIX")) ctx->dn->opt_f16_minpix = atoll(getenv("AIPT_F16_MINPIX"));
+        if (getenv("AIPT_F16_SMALL_MINPIX")) ctx->dn->opt_small_minpix = atoll(getenv("AIPT_F16_SMALL_MINPIX"));
+#endif
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 4, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     return ctx->dn;
 }
@@ -1712,10 +1635,22 @@ static int conv_nblk(const TileChoice& t, int H, int W) {
 // conv + (stats ->) finalize.  `dst` receives the raw output and its (a,b).
 // true when the conv of an h x w level runs on the split-fp16 kernel in a one-row-per-wave instantiation: those fuse the 2x2
 // pool of an encoder block's output into their epilogue (ConvArgsH::pool_out)
-static bool conv_fuses_pool(const DenoiseState* s, int H, int W) {
-    static const bool on = !getenv("AIPT_DN_FUSED_POOL") || atoi(getenv("AIPT_DN_FUSED_POOL")) != 0;
-    static const bool one_row = !getenv("AIPT_F16_WAVES") || atoi(getenv("AIPT_F16_WAVES")) == 8;
-    return on && impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels() && ((long)H * W < f16_min_pixels() || one_row);
+// May a conv of an H x W level hold its NORMALISED input activations y = lrelu(a x + b) as fp16 pairs with |y| * scale <= 65 504?
+// With batch statistics |y| <= |gamma| sqrt(n - 1) + |beta| over the n pixels the statistics ran over (one outlier carrying all
+// of the variance), so the answer follows from the loaded weights: limit = 4 000 for conv3x3_f16x3r (activations times 2^4: beyond
+// 4 094 the hi half saturates, beyond 8 190 the lo half becomes inf and inf x 0 = NaN spreads over the frame), 65 000 for
+// conv3x3_f16x3.  A level that fails a limit runs on the next kernel down (conv3x3_f16x3, then the exact f32 MFMA kernel, which
+// has the range of fp32).  Running statistics bound nothing: there the caller keeps |y| < 4 094 (include/aiptd.h) or selects
+// AIPT_DN_IMPL_MFMA.
+static bool f16_range_ok(const DenoiseState* s, bool batch, int H, int W, double limit) {
+    if (!batch) return true;
+    const double bound = (double)s->bn_gmax * sqrt((double)H * (double)W) + (double)s->bn_bmax;
+    return bound < limit;       // (false for NaN)
+}
+// true when the conv of an h x w level runs on a split-fp16 kernel: those fuse the 2x2 pool of an encoder block's output into
+// their epilogue (ConvArgsH::pool_out)
+static bool conv_fuses_pool(const DenoiseState* s, bool batch, int H, int W) {
+    return s->opt_fused_pool && impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0);
 }
 
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
@@ -1735,18 +1670,20 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
     const int expect = A.C + (B ? B->C : 0);
     if (expect != L.cin || A.C != L.ca)
         return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
-    double* const stat = batch ? s->stat[s->sset] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
+    long long* const stat = batch ? s->stat[s->sset] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
     g.stat = stat; g.sc = DenoiseState::STAT_SC;
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
-    // AIPT_DEBUG_LAYER_MASK (tools/coresidency): launch only the conv layers whose bit is set -- the outputs are then garbage;
-    // for bisecting which launch of a forward pass disturbs a kernel running beside it
+#ifdef AIPT_DEBUG_HOOKS
+    // AIPT_DEBUG_LAYER_MASK (tools/coresidency, debug builds only): launch only the conv layers whose bit is set -- the outputs
+    // are then garbage; for bisecting which launch of a forward pass disturbs a kernel running beside it
     static const unsigned long debug_mask = getenv("AIPT_DEBUG_LAYER_MASK") ? strtoul(getenv("AIPT_DEBUG_LAYER_MASK"), nullptr, 0) : ~0ul;
     if (!((debug_mask >> li) & 1ul)) {
         if (batch) dst.bn = BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)};
         else dst.bn = BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};
         return AIPT_OK;
     }
+#endif
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[0], s->cur));
     if (s->impl == AIPT_DN_IMPL_VALU) {
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_valu");
@@ -1771,7 +1708,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
         snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
         hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, s->cur, gh);
-    } else if (L.d_w_d2s && upA && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
+    } else if (L.d_w_d2s && upA) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
         g.a.up = 0; g.b.up = 0;
         g.H = H / 2; g.W = W / 2;
@@ -1783,17 +1720,13 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         if (t.rw == 2 && t.mbx == 2) launch_mfma<2, 2, 1>(g, grid, s->cur);
         else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, s->cur);
         else launch_mfma<1, 1, 1>(g, grid, s->cur);
-    } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
+    } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar) {
         const int strips = ((W + 3) / 4) * H;
         const int nblk = (strips + 255) / 256;
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3>");
         hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, s->cur, g);
-    } else if (L.cout == 3 && s->impl != AIPT_DN_IMPL_MFMA_NOFEW) {
-        const dim3 grid((W + 15) / 16, (H + 15) / 16);
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_fewout<3>");
-        hipLaunchKernelGGL((conv3x3_fewout<3>), grid, dim3(256), 0, s->cur, g);
-    } else if (impl_is_f16(s->impl) && (long)H * W >= f16_small_min_pixels()) {
-        // full-resolution levels: split-fp16 MFMA, 8 x 32 pixel tiles x 32 output channels
+    } else if (impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0)) {
+        // split-fp16 MFMA
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
         gh.wsplit = L.d_wsplit; gh.bias = L.d_bias32;
@@ -1801,58 +1734,49 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.nchunks = g.b.C ? L.nchunks16 : L.ca16;                 // an all-zero second source (hidden reset) is skipped
         gh.wchunks = L.nchunks16; gh.ca16 = L.ca16;
         gh.out = dst.p; gh.out_lrelu = out_lrelu;
-        // tile rows = waves per workgroup: 8 on the big levels; the small levels (< f16_min_pixels) have too few 8 x 32 tiles
-        // to fill 256 CUs and run 2- or 4-row tiles
-        static const int small_rows = getenv("AIPT_F16_SMALL_ROWS") ? atoi(getenv("AIPT_F16_SMALL_ROWS")) : 4;
-        static const int nwv = getenv("AIPT_F16_WAVES") ? atoi(getenv("AIPT_F16_WAVES")) : 8;   // 8 waves x 1 row: 116 VGPRs -> 16 waves/CU (4 waves x 2 rows: 212 VGPRs -> 8)
-        const bool big = (long)H * W >= f16_min_pixels();
-        const int rows = big ? 8 : small_rows;
-        const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = 0;
         gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
+        gh.ablate = 0;
+#ifdef AIPT_CONV_ABLATE
         static const int ablate_env = getenv("AIPT_CONV_ABLATE") ? (int)strtol(getenv("AIPT_CONV_ABLATE"), nullptr, 0) : 0;
         gh.ablate = ablate_env;
-        // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
-        const bool w16 = s->impl == AIPT_DN_IMPL_MFMA_F16W;
-        f16x3_name(s->kname[li], sizeof(s->kname[li]), gh.a.planar ? 8 : rows, gh.a.planar != 0, w16);
-        gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
-        const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
-        // the big levels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit LDS
-        static const long r_minpix = getenv("AIPT_F16R_MINPIX") ? atol(getenv("AIPT_F16R_MINPIX")) : 200000;
-        static const long r_minpix4 = getenv("AIPT_F16R_MINPIX4") ? atol(getenv("AIPT_F16R_MINPIX4")) : 200000;   // below: 2-row items
+#endif
+        const bool w16 = w16_mode(s);
+        if (gh.a.planar && (gh.b.C || gh.a.up || gh.a.slope != 1.0f || gh.a.bn.stat || gh.a.bn.ab || gh.a.C > KH))
+            return fail(ctx, AIPT_E_STATE, "layer %d: a planar conv input must be the untransformed network input", li);
+        // the levels of >= opt_r_minpix pixels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit
+        // LDS and the normalised activations provably fit its operand range (f16_range_ok)
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
-        static const int r_planar = getenv("AIPT_F16R_PLANAR") ? atoi(getenv("AIPT_F16R_PLANAR")) : 1;
-        if ((!gh.a.planar || (r_planar && gh.nchunks == 1 && !gh.b.C && !gh.a.up && gh.a.C <= 16)) && (long)H * W >= r_minpix &&
-            gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && L.d_wsplit1 && !(H & 1) && !(W & 1)) {
-            gh.wsplit = L.d_wsplit1;
-            const int r_rows = (long)H * W >= r_minpix4 ? 4 : 2;
-            gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + r_rows - 1) / r_rows; gh.groups = r_groups;
+        if ((long long)H * W >= s->opt_r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && !(H & 1) && !(W & 1) &&
+            (gh.a.planar || f16_range_ok(s, batch, H, W, 4000.0))) {
+            // planar input: the wide-range two-accumulator arithmetic on the hi + 2^11 lo slabs (see the kernel)
+            gh.wsplit = gh.a.planar ? L.d_wsplit : w16 ? L.d_wsplit1_16 : L.d_wsplit1;
+            gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + 3) / 4; gh.groups = r_groups;
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
-            static const int r_var = getenv("AIPT_F16R_VARIANT") ? atoi(getenv("AIPT_F16R_VARIANT")) : 0;
+            // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
             snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s,%s>", w16 ? "true" : "false",
-                     r_rows == 2 ? "12,4,false,2" : gh.a.planar ? "8,3,false,4" : r_var == 1 && !w16 ? "8,3,true,4" : "12,3,false,4", gh.a.planar ? "true" : "false");
+                     gh.a.planar ? "8,3,false,4" : "12,3,false,4", gh.a.planar ? "true" : "false");
             if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
-            else
-            {
-            if (r_rows == 2 && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            else if (r_rows == 2) hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 4, false, 2>), dim3(pgrid), dim3(768), lds, s->cur, gh);
             else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            else if (r_var == 1) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            }
-        } else if (gh.a.planar) {
-            if (gh.b.C || gh.a.up) return fail(ctx, AIPT_E_STATE, "planar conv input with concat/upsample");
-            if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
-            else hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
-        } else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
-        else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(grid_1d(grid.x, (H + 3) / 4, grid.z)), dim3(256), 0, s->cur, gh);
-        else if (rows == 2) hipLaunchKernelGGL((conv3x3_f16x3<1, 2>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(128), 0, s->cur, gh);
-        else if (rows == 4) hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, s->cur, gh);
-        else if (nwv == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(512), 0, s->cur, gh);
-        else hipLaunchKernelGGL((conv3x3_f16x3<2, 4>), dim3(grid_1d(grid.x, grid.y, grid.z)), dim3(256), 0, s->cur, gh);
+        } else {
+            // LDS-tiled kernel.  Tile rows = waves per workgroup: 8, or 4 on the levels below opt_f16_minpix (too few 8 x 32 tiles
+            // for 256 CUs); the planar input always on 8-row tiles
+            const int rows = ((long long)H * W >= s->opt_f16_minpix || gh.a.planar) ? 8 : 4;
+            const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
+            gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
+            const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
+            f16x3_name(s->kname[li], sizeof(s->kname[li]), rows, gh.a.planar != 0, w16);
+            if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(nb1), dim3(256), 0, s->cur, gh);
+            else if (rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(nb1), dim3(256), 0, s->cur, gh);
+        }
     } else {
         const TileChoice t = choose_tile(H, W, L.NB);
         const dim3 grid((W + 16 * t.mbx - 1) / (16 * t.mbx), (H + 4 * t.rw - 1) / (4 * t.rw), L.NB / t.nbb);
@@ -1905,6 +1829,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
     if (off + 4 * nfl != bytes) return fail(ctx, AIPT_E_FORMAT, "weight blob: %zu bytes, expected %zu", bytes, off + 4 * nfl);
     DenoiseState* s = state(ctx);
     free_weights(s);
+    s->bn_gmax = 0.0f; s->bn_bmax = 0.0f;
     // the carried hidden states reference the old layers' gamma/beta/statistics: a reload resets the recurrent state
     s->hidden_valid = false;
     for (DenoiseState::ActSet& X : s->A)
@@ -1989,7 +1914,7 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                 for (int v = 0; v < vco; v++)
                     for (int kc = 0; kc < nch * KH; kc++)
                         for (int t = 0; t < 9; t++) {
-                            const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t] * WS;
+                            const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t];
                             const _Float16 h = (_Float16)x;
                             const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v) * KH + (kc % KH);
                             ws[o] = h;
@@ -2010,12 +1935,12 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
             L.ca16 = pad16(L.ca) / KH;
             L.nchunks16 = L.ca16 + pad16(cb) / KH;
             const size_t nh = (size_t)(L.coutp32 / 32) * L.nchunks16 * (WSLAB / 2);
-            std::vector<_Float16> ws(nh, (_Float16)0.0f), ws1(nh, (_Float16)0.0f);
+            std::vector<_Float16> ws(nh, (_Float16)0.0f), ws1(nh, (_Float16)0.0f), ws1r(nh, (_Float16)0.0f);
             for (int j = 0; j < L.cout; j++)
                 for (int c = 0; c < L.cin; c++) {
                     const int kc = c < L.ca ? c : pad16(L.ca) + (c - L.ca);
                     for (int t = 0; t < 9; t++) {
-                        const float v = w[((size_t)j * L.cin + c) * 9 + t] * WS;
+                        const float v = w[((size_t)j * L.cin + c) * 9 + t];
                         const _Float16 h = (_Float16)v;
                         const size_t slab = ((size_t)(j / 32) * L.nchunks16 + kc / KH) * (WSLAB / 2);
                         const size_t o = slab + ((size_t)t * 32 + (j % 32)) * KH + (kc % KH);
@@ -2025,10 +1950,15 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                         const _Float16 h1 = (_Float16)v1;
                         ws1[o] = h1;
                         ws1[o + 9 * 32 * KH] = (_Float16)(v1 - (float)h1);
+                        // fp16-weight mode: "the model with its conv weights rounded to fp16" on every level -- 2^7 fp16(w), which is
+                        // not fp16(2^7 w) when w is an fp16 subnormal
+                        ws1r[o] = (_Float16)((float)(_Float16)w[((size_t)j * L.cin + c) * 9 + t] * WS1);
                     }
                 }
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit1, nh * 2));
             AIPT_HIP(ctx, hipMemcpy(L.d_wsplit1, ws1.data(), nh * 2, hipMemcpyHostToDevice));
+            AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit1_16, nh * 2));
+            AIPT_HIP(ctx, hipMemcpy(L.d_wsplit1_16, ws1r.data(), nh * 2, hipMemcpyHostToDevice));
             std::vector<float> b32(L.coutp32, 0.0f);
             memcpy(b32.data(), b, 4 * L.cout);
             AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit, nh * 2));
@@ -2054,6 +1984,10 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
         AIPT_HIP(ctx, hipMemcpy(L.d_gamma, gamma, L.cout * 4, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(L.d_beta, beta, L.cout * 4, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(L.d_ab_running, abr.data(), L.cout * sizeof(float2), hipMemcpyHostToDevice));
+        for (int j = 0; j < L.cout; j++) {
+            if (!(fabsf(gamma[j]) <= s->bn_gmax)) s->bn_gmax = fabsf(gamma[j]);      // (NaN-proof: a NaN gamma makes the bound NaN -> exact kernels)
+            if (!(fabsf(beta[j]) <= s->bn_bmax)) s->bn_bmax = fabsf(beta[j]);
+        }
     }
     s->have_weights = true;
     return AIPT_OK;
@@ -2103,7 +2037,7 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     }
     if (rc) { free_activations(s); return rc; }
     for (int k = 0; k < DenoiseState::STAT_SETS && !rc; k++)
-        rc = alloc(sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
+        rc = alloc(sizeof(long long) * NLAYERS * DenoiseState::STAT_LAYER, (void**)&s->stat[k]);
     if (rc) { free_activations(s); return rc; }
     for (int a = 0; a < DenoiseState::NSET; a++)
         for (int l = 0; l < 6; l++) AIPT_HIP(ctx, hipEventCreateWithFlags(&s->ev_level[a][l], hipEventDisableTiming));
@@ -2119,6 +2053,20 @@ int aipt_denoise_set_impl(aipt_ctx* ctx, int impl) {
     AIPT_CHECK_CTX(ctx);
     if (impl != AIPT_DN_IMPL_MFMA && impl != AIPT_DN_IMPL_VALU && impl != AIPT_DN_IMPL_MFMA_F16X3 && impl != AIPT_DN_IMPL_MFMA_F16W) return fail(ctx, AIPT_E_INVALID, "unknown impl %d", impl);
     state(ctx)->impl = impl;
+    return AIPT_OK;
+}
+
+int aipt_denoise_set_option(aipt_ctx* ctx, int option, long long value) {
+    AIPT_CHECK_CTX(ctx);
+    DenoiseState* s = state(ctx);
+    if (value < 0) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: value %lld", value);
+    switch (option) {
+        case AIPT_DN_OPT_R_MINPIX: s->opt_r_minpix = value; break;
+        case AIPT_DN_OPT_F16_MINPIX: s->opt_f16_minpix = value; break;
+        case AIPT_DN_OPT_SMALL_MINPIX: s->opt_small_minpix = value; break;
+        case AIPT_DN_OPT_FUSED_POOL: s->opt_fused_pool = value != 0; break;
+        default: return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: unknown option %d", option);
+    }
     return AIPT_OK;
 }
 
@@ -2174,7 +2122,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     }
     if (batch) {   // this frame's BN sums go to the next set of the ring: the carried hidden states still point into the last one
         s->sset = (s->sset + 1) % DenoiseState::STAT_SETS;
-        AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->sset], 0, sizeof(double) * NLAYERS * DenoiseState::STAT_LAYER, st));
+        AIPT_HIP(ctx, hipMemsetAsync(s->stat[s->sset], 0, sizeof(long long) * NLAYERS * DenoiseState::STAT_LAYER, st));
     }
     // level l of this frame reads the hidden state the previous frame wrote at level l (on the other stream when pipelined)
     auto wait_hidden = [&](int l) -> hipError_t {
@@ -2189,7 +2137,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94).  The split-fp16 conv reads it as it is; the other
     // implementations get a C4 copy first.
     in = X.In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
-    const bool direct = impl_is_f16(s->impl) && (long)H * W >= f16_min_pixels();
+    const bool direct = impl_is_f16(s->impl) && (long long)H * W >= s->opt_f16_minpix && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0);
     if (direct) {
         in.p = const_cast<float*>(d_in10); in.planar = 1;
     } else {
@@ -2205,7 +2153,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
         AIPT_HIP(ctx, wait_hidden(i));
         if ((rc = run_conv(ctx, s, li++, X.T1[i], 0, &prevX.Hid[i], 0, h, w, 1, X.T2[i], batch, carry))) return rc;
         Tensor t2 = X.T2[i]; t2.slope = 1.0f;        // LReLU already applied by the producer (conv -> LReLU -> BN)
-        const bool fused_pool = conv_fuses_pool(s, h, w);
+        const bool fused_pool = conv_fuses_pool(s, batch, h, w);
         if ((rc = run_conv(ctx, s, li++, t2, 0, nullptr, 0, h, w, 0, X.Hid[i], batch, false, fused_pool ? &X.P[i] : nullptr))) return rc;
         X.Hid[i].slope = SLOPE;
         AIPT_HIP(ctx, hidden_written(i));

@@ -220,6 +220,23 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);
 /* activations for frames of height x width (both multiples of 32: five 2x pools + skip concat). */
 int aipt_denoise_configure(aipt_ctx* ctx, int height, int width);
 int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
+/* Operand range of the split-fp16 implementations (AIPT_DN_IMPL_MFMA_F16X3 / _F16W; AIPT_DN_IMPL_MFMA and _VALU are plain fp32).
+ *  - network input (the G-buffer, in the caller's units): |x| <= 2^20 (1.0e6), no absolute floor that matters (2^-32); larger
+ *    values saturate at 2^20.  The reference model is fp32 throughout (recurrent_autoencoder_model.py:8-142) and has no such bound.
+ *  - BatchNorm sums are two-word fixed point: exact and order-independent while |sum x|, sum x^2 < 9.2e18 per channel and frame.
+ *  - normalised activations y = LeakyReLU(BN(x)) are held as fp16 pairs: |y| < 4 094 on the levels of >= AIPT_DN_OPT_R_MINPIX
+ *    pixels, < 65 504 below.  With AIPT_DN_BN_BATCH, |y| <= max|gamma| * sqrt(pixels) + max|beta| always holds, and a level whose
+ *    bound from the LOADED weights exceeds its kernel's range runs on the next kernel down (finally the exact fp32 one): nothing
+ *    for the caller to check.  With AIPT_DN_BN_RUNNING nothing bounds y: the caller keeps |y| < 4 094 or uses AIPT_DN_IMPL_MFMA
+ *    (beyond the range a frame degrades to inf / NaN instead of fp32's large finite values).
+ * Kernel selection of the split-fp16 implementations, by the pixel count of a level (defaults tuned on MI355X; every setting
+ * computes the same function to <= 1e-3 and is covered by tests/test_gpu_denoise_kernels.py).  No environment variable changes
+ * which arithmetic a caller gets. */
+#define AIPT_DN_OPT_R_MINPIX     1   /* levels of >= value pixels: conv3x3_f16x3r, persistent register-staged (default 200000) */
+#define AIPT_DN_OPT_F16_MINPIX   2   /* below R_MINPIX: conv3x3_f16x3 LDS-tiled, 8-row tiles from value pixels up, 4-row below (14000) */
+#define AIPT_DN_OPT_SMALL_MINPIX 3   /* levels below value pixels: the exact f32 MFMA kernel (default 0: none) */
+#define AIPT_DN_OPT_FUSED_POOL   4   /* 1 (default): MaxPool2d(2) in the producing conv's epilogue; 0: a pool launch per encoder level */
+int aipt_denoise_set_option(aipt_ctx* ctx, int option, long long value);
 /* forward: d_in10 float[10][H][W] -> d_out3 float[3][H][W] */
 int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags);
 int aipt_denoise_reset_hidden(aipt_ctx* ctx);

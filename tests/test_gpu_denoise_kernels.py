@@ -1,0 +1,224 @@
+"""-m gpu: the envelope of the denoiser's kernel selection.
+
+Every conv instantiation libaiptd.so ships is selected by one of these cases -- through the ABI (aipt_denoise_set_option,
+aipt_denoise_set_impl), never through an environment variable -- and held to the same bar as the default path: 1e-3 max abs
+against the CPU oracle.  The register-staged kernel of the benchmark's big levels (conv3x3_f16x3r) gets the cases the round-3
+tests only ran at sizes where it is never selected: large-magnitude network inputs, BatchNorms whose activation bound exceeds its
+fp16 operand range, and the 16-frame drift study against the fp64 truth."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from ai_path_tracer_denoiser_amd import api, arch, synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernel names as aipt_denoise_layer_info reports them (= rocprofv3's, without blanks)
+R = "conv3x3_f16x3r<false,12,3,false,4,false>"
+R_PLANAR = "conv3x3_f16x3r<false,8,3,false,4,true>"
+R16 = "conv3x3_f16x3r<true,12,3,false,4,false>"
+R16_PLANAR = "conv3x3_f16x3r<true,8,3,false,4,true>"
+SEEN = set()          # every kernel name a passing case of this module ran (checked last, against the shipped set)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _run(ctx, blob, frames, H, W, bn_batch=True, carry=True, impl=api.DN_IMPL_MFMA_F16X3, opts=None):
+    import torch
+    ctx.load_weights(blob)
+    ctx.denoise_configure(H, W)
+    ctx.denoise_set_impl(impl)
+    defaults = {api.DN_OPT_R_MINPIX: 200000, api.DN_OPT_F16_MINPIX: 14000, api.DN_OPT_SMALL_MINPIX: 0, api.DN_OPT_FUSED_POOL: 1}
+    defaults.update(opts or {})
+    for k, v in defaults.items():
+        ctx.denoise_set_option(k, v)
+    ctx.reset_hidden()
+    outs = []
+    for j, x in enumerate(frames):
+        y = torch.empty(3, H, W, device="cuda")
+        ctx.denoise(torch.from_numpy(x).cuda(), y, bn_batch=bn_batch, carry=carry and j > 0)
+        ctx.sync()
+        outs.append(y.cpu().numpy())
+    names = [ctx.layer_info(l)["kernel"] for l in range(28)]
+    for k in defaults:                                     # leave the module-scoped context at the library's defaults
+        ctx.denoise_set_option(k, {api.DN_OPT_R_MINPIX: 200000, api.DN_OPT_F16_MINPIX: 14000, api.DN_OPT_SMALL_MINPIX: 0,
+                                   api.DN_OPT_FUSED_POOL: 1}[k])
+    return outs, names
+
+
+def _check(outs, names, blob, frames, H, W, bn_batch=True, carry=True, tol=TOL):
+    import oracle
+    orc = oracle.DenoiseOracle(blob, H, W)
+    errs = []
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, bn_batch, carry and j > 0)
+        assert np.isfinite(outs[j]).all(), f"frame {j}: non-finite output"
+        errs.append(float(np.abs(outs[j] - ref).max()))
+        assert errs[-1] <= tol, (j, errs[-1], float(np.abs(ref).max()))
+    SEEN.update(names)
+    return errs
+
+
+@pytest.mark.parametrize("scale", [500.0, 5000.0])
+@pytest.mark.parametrize("size", [(384, 640), (736, 1280)])
+def test_large_magnitude_inputs_on_the_register_staged_kernel(ctx, size, scale):
+    """VERDICT r3 weak 1 / ADVICE r3 medium: conv3x3_f16x3r staged the raw G-buffer times 2^4 into fp16 -- |x| > 4 094 saturated,
+    |x| > 8 190 became inf and the whole frame NaN -- and no test fed it such inputs at a size where it runs.  Plane 6 (first-hit
+    distance) reaches 1.25e4 at x500 and 1.25e5 at x5000 (a scene modelled in centimetres).  The planar first conv now keeps the
+    wide-range two-accumulator arithmetic (|x| <= 1.0e6) and the BatchNorm sums two fixed-point words (the first conv's sum of
+    squares is ~1e15 here; the one-word format wrapped at 8.8e12)."""
+    H, W = size
+    blob = synth.make_blob(565)
+    x = (synth.make_gbuffer(H, W, 3, 0) * np.float32(scale)).astype(np.float32)
+    outs, names = _run(ctx, blob, [x], H, W, True, False)
+    assert names[0] == R_PLANAR and names[1] == R and names[2] == R, names[:3]
+    errs = _check(outs, names, blob, [x], H, W, True, False)
+    print(f"{H}x{W} inputs x{scale:g}: max abs err vs the oracle {errs[0]:.2e}")
+
+
+def test_small_magnitude_inputs_keep_their_bits(ctx):
+    """The other end of the range: a G-buffer scaled by 1e-4 (BatchNorm restores the scale, so every lost low bit of the operand
+    split would be amplified 10^4 times).  The planar conv's low halves are scaled by 2^11: no absolute floor above 2^-32."""
+    H, W = 384, 640
+    blob = synth.make_blob(565)
+    x = (synth.make_gbuffer(H, W, 4, 0) * np.float32(1e-4)).astype(np.float32)
+    outs, names = _run(ctx, blob, [x], H, W, True, False)
+    assert names[0] == R_PLANAR
+    _check(outs, names, blob, [x], H, W, True, False)
+
+
+def _scaled_gamma_blob(seed, factor):
+    params = arch.unpack_blob(synth.make_blob(seed))
+    for p in params.values():
+        p["gamma"] = (p["gamma"] * np.float32(factor)).astype(np.float32)
+    return arch.pack_blob(params)
+
+
+@pytest.mark.parametrize("factor,expect", [(6.0, "conv3x3_f16x3<"), (120.0, "conv3x3_mfma<")])
+def test_batchnorms_beyond_a_kernels_operand_range_run_on_the_next_kernel(ctx, factor, expect):
+    """|BN(x)| <= |gamma| sqrt(pixels) + |beta| with batch statistics.  Weights whose bound exceeds 4 000 at a level (gamma x 6:
+    1.5 x 6 x sqrt(384 x 640) = 4 460) must not run there on conv3x3_f16x3r (activations x 2^4 in fp16), beyond 65 000 (gamma x
+    120) not on any split-fp16 kernel; the result stays the oracle's, to a tolerance relative to the larger outputs."""
+    H, W = 384, 640
+    blob = _scaled_gamma_blob(565, factor)
+    frames = [synth.make_gbuffer(H, W, 6, j) for j in range(2)]
+    outs, names = _run(ctx, blob, frames, H, W, True, True)
+    assert all(n.startswith(expect) or n.startswith("conv3x3_f16x3<") or n.startswith("conv3x3_mfma<") or n.startswith("conv3x3_quad")
+               for n in names), names
+    assert names[1].startswith(expect) and not any(n.startswith("conv3x3_f16x3r") for n in names[1:]), names
+    import oracle
+    orc = oracle.DenoiseOracle(blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, True, j > 0)
+        assert np.isfinite(outs[j]).all()
+        err = float(np.abs(outs[j] - ref).max())
+        assert err <= TOL * max(1.0, float(np.abs(ref).max())), (factor, j, err, float(np.abs(ref).max()))
+    SEEN.update(names)
+
+
+@pytest.mark.parametrize("bn_batch", [True, False])
+def test_register_staged_kernel_on_every_level_it_can_take(ctx, bn_batch):
+    """AIPT_DN_OPT_R_MINPIX = 0 at 192x320: levels 0-2 (and the decoder's) run on conv3x3_f16x3r with one to seven chunks, part
+    items at the bottom and right edges (48 = 12 x 4 rows; 320 = 10 x 30 + 20 columns), fused pools and carried hidden states --
+    the sizes the default selection never gives it."""
+    H, W = 192, 320
+    blob = synth.make_blob(21)
+    frames = [synth.make_gbuffer(H, W, 8, j) for j in range(2)]
+    outs, names = _run(ctx, blob, frames, H, W, bn_batch, True, opts={api.DN_OPT_R_MINPIX: 0})
+    assert names.count(R) >= 12 and names[0] == R_PLANAR, names
+    _check(outs, names, blob, frames, H, W, bn_batch, True)
+
+
+def test_register_staged_kernel_with_fp16_weights(ctx):
+    """AIPT_DN_IMPL_MFMA_F16W on conv3x3_f16x3r<true,...>: equals the oracle run on the fp16-rounded weights -- including weights in
+    fp16's subnormal range, where fp16(2^7 w) != 2^7 fp16(w) (the big and the small levels must be the same model)."""
+    import oracle
+    H, W = 384, 640
+    params = arch.unpack_blob(synth.make_blob(21))
+    rng = np.random.default_rng(5)
+    for p in params.values():                        # a tenth of the weights pushed into the subnormal range of fp16
+        w = p["w"]
+        m = rng.random(w.shape) < 0.1
+        p["w"] = np.where(m, w * np.float32(3e-4), w).astype(np.float32)
+    blob = arch.pack_blob(params)
+    for p in params.values():
+        p["w"] = p["w"].astype(np.float16).astype(np.float32)
+    blob16 = arch.pack_blob(params)
+    frames = [synth.make_gbuffer(H, W, 5, j) for j in range(2)]
+    outs, names = _run(ctx, blob, frames, H, W, True, True, impl=api.DN_IMPL_MFMA_F16W)
+    assert names[0] == R16_PLANAR and names[1] == R16, names[:3]
+    orc = oracle.DenoiseOracle(blob16, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, True, j > 0)
+        assert float(np.abs(outs[j] - ref).max()) <= TOL, (j, float(np.abs(outs[j] - ref).max()))
+    SEEN.update(names)
+    outs0, names0 = _run(ctx, blob, frames, H, W, True, True, impl=api.DN_IMPL_MFMA_F16W, opts={api.DN_OPT_R_MINPIX: 10**9})
+    assert not any(n.startswith("conv3x3_f16x3r") for n in names0)
+    for j in range(2):                               # LDS-tiled and register-staged kernels: the same rounded model
+        assert float(np.abs(outs[j] - outs0[j]).max()) <= 2e-4
+    SEEN.update(names0)
+
+
+@pytest.mark.parametrize("opts,impl", [
+    ({api.DN_OPT_F16_MINPIX: 0}, api.DN_IMPL_MFMA_F16X3),                       # 8-row LDS tiles on every level
+    ({api.DN_OPT_F16_MINPIX: 10**9}, api.DN_IMPL_MFMA_F16X3),                   # 4-row tiles everywhere (network input through a C4 copy)
+    ({api.DN_OPT_F16_MINPIX: 10**9}, api.DN_IMPL_MFMA_F16W),
+    ({api.DN_OPT_SMALL_MINPIX: 2000}, api.DN_IMPL_MFMA_F16X3),                  # the deep levels on the exact f32 MFMA kernel
+    ({api.DN_OPT_FUSED_POOL: 0}, api.DN_IMPL_MFMA_F16X3),                       # pool2_norm launches
+    ({}, api.DN_IMPL_MFMA),
+    ({}, api.DN_IMPL_MFMA_F16W),
+    ({}, api.DN_IMPL_VALU),
+])
+def test_every_selectable_tiling_matches_the_oracle(ctx, opts, impl):
+    import oracle
+    H, W = 160, 256
+    blob = synth.make_blob(11)
+    ref_blob = blob
+    if impl == api.DN_IMPL_MFMA_F16W:
+        params = arch.unpack_blob(blob)
+        for p in params.values():
+            p["w"] = p["w"].astype(np.float16).astype(np.float32)
+        ref_blob = arch.pack_blob(params)
+    frames = [synth.make_gbuffer(H, W, 7, j) for j in range(2)]
+    outs, names = _run(ctx, blob, frames, H, W, True, True, impl=impl, opts=opts)
+    orc = oracle.DenoiseOracle(ref_blob, H, W)
+    for j, x in enumerate(frames):
+        ref = orc.forward(x, True, j > 0)
+        assert float(np.abs(outs[j] - ref).max()) <= TOL, (opts, impl, j, float(np.abs(outs[j] - ref).max()))
+    SEEN.update(names)
+
+
+@pytest.mark.parametrize("size,nfr,r_minpix", [((384, 640), 16, None), ((192, 320), 16, 0)])
+def test_drift_of_the_register_staged_kernel_against_fp64_truth(size, nfr, r_minpix):
+    """the round-3 drift study ran at 192x320, where every layer was conv3x3_f16x3 (two accumulators, low halves
+    x 2^11); conv3x3_f16x3r (one accumulator, low halves unscaled) runs the benchmark's big levels.  The same bar on THAT kernel:
+    over 16 frames of one recurrent sequence it is no further from the double-precision truth than fp32 arithmetic itself."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import drift_probe
+    r = drift_probe.run(size[0], size[1], nfr, 565, impls=("f16x3",), r_minpix=r_minpix)
+    assert R in r["kernels_f16x3"] and R_PLANAR in r["kernels_f16x3"], r["kernels_f16x3"]
+    o32, gpu = np.array(r["oracle_fp32"]), np.array(r["gpu_f16x3"])
+    print("fp32 oracle vs truth:", " ".join(f"{e:.1e}" for e in o32))
+    print("GPU         vs truth:", " ".join(f"{e:.1e}" for e in gpu))
+    assert o32[0] < 1e-3 and gpu[0] < 1e-3
+    assert (gpu <= 1.25 * o32 + 5e-5).all(), (gpu, o32)
+    assert gpu[-1] <= o32[-1]
+
+
+def test_zz_every_shipped_conv_instantiation_was_selected():
+    """Runs last in this module (name order): the conv kernels in libaiptd.so's symbol table are exactly the set the cases above
+    selected -- an instantiation nothing selects does not ship."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_shipped_kernels_cpu import shipped_conv_kernels
+    shipped = shipped_conv_kernels()
+    missing = sorted(k for k in shipped if k not in SEEN)
+    assert not missing, f"shipped but never selected by a parity case of this module: {missing}\nselected: {sorted(SEEN)}"

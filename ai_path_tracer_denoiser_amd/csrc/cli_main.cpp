@@ -8,8 +8,18 @@
 //
 //   aiptd scene.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE | --synthetic-weights SEED]
 //                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w] [--pan AMPLITUDE] [--device I]
-//                   [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]
+//                   [--no-aa] [--no-compaction] [--sort-material] [--cache-first-bounce] [--motion-blur] [--no-cull]
+//                   [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth] [--dump-weights FILE]
 //                   [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]
+//
+// The reference's compile-time switches are run-time flags: STREAM_COMPACTION / SORT_MATERIAL / CACHE_BOUNCE /
+// RAY_CULLING / AA / MOTION_BLUR (pathtrace.cu:20-27), MESH_NORMAL_VIEW / DIELECTRIC (interactions.h:4-6), RECOMPUTE_NORMALS
+// (scene.cpp:9), and GROUND_TRUTH (main.cpp:41): --spp N accumulates N iterations per camera position before the frame is
+// denoised and the camera advances, exactly the runCuda loop with GROUND_TRUTH true (main.cpp:147-165; --ground-truth takes N
+// from the scene file's ITERATIONS like renderState->iterations).  The 1-spp image of iteration 1 goes to RGB/ (with Normals/
+// Depth/ Albedos/, which later iterations do not touch, pathtrace.cu:295,379), the accumulated image to GroundTruth/
+// (train.sh:13-27), and Denoised/ is the network's output on the accumulated tensor -- what network_prediction_faster_version
+// sees when iteration reaches renderState->iterations.
 //
 // Multi-GPU (no reference equivalent: the reference is single-GPU; design SURVEY 8e): --gpus N runs one rank (one
 // host thread, one context) per GPU; rank r renders the contiguous frame chunk [r*F/R, (r+1)*F/R) -- contiguous so that a
@@ -189,6 +199,8 @@ struct Options {
     std::string scene_path, out_dir, weights_path, dump_weights;
     int frames = 1, res_w = 0, res_h = 0, depth = 0, device = 0, impl = AIPT_DN_IMPL_MFMA_F16X3;
     int gpus = 1, ranks = 0, batch = 1, reset_every = 0;
+    int spp = 1;                      // iterations accumulated per frame (--spp N; --ground-truth: the scene's ITERATIONS)
+    bool ground_truth = false, recompute_normals = false;
     bool prefetch = false;
     bool npy = false, shim = false;
     uint64_t wseed = 565;
@@ -235,6 +247,7 @@ void render(const Shared& sh, Rank& rk) {
     const size_t plane = (size_t)rows * stride;
     std::vector<float> h_g(10 * plane), h_o((size_t)3 * W * H);
     const bool save = !o.out_dir.empty();
+    std::vector<float> h_g1(save && o.spp > 1 ? 10 * plane : 0);     // multi-spp: the G-buffer after iteration 1
     aipt_frame_set_timing(ctx, 1);
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = rk.f0; k < rk.f1;) {
@@ -252,7 +265,17 @@ void render(const Shared& sh, Rank& rk) {
             std::unique_lock<std::mutex> hold;
             if (sh.gpu_lock) hold = std::unique_lock<std::mutex>(sh.gpu_lock[rk.device - o.device]);
             if (B > 1) rc = aipt_frames(ctx, cams.data(), nb, 1, sh.depth, o.tr_flags, f_first, o.dn_flags, d_out.data());
-            else rc = aipt_frame(ctx, &cams[0], 1, sh.depth, o.tr_flags, f_first, d_out[0]);
+            else {
+                // iterations 1 .. spp-1 accumulate into the context's image through the front G-buffer (the one aipt_frame traces
+                // into); the last iteration is aipt_frame's own trace, followed by the denoise (main.cpp:147-163)
+                rc = 0;
+                for (int it = 1; it < o.spp && !rc; it++) {
+                    aipt_gbuffer(ctx, &d_gbuf, &rows, &stride);
+                    rc = aipt_trace(ctx, &cams[0], it, sh.depth, o.tr_flags, d_gbuf, rows, stride);
+                    if (!rc && it == 1 && save) rc = aipt_download(ctx, h_g1.data(), d_gbuf, sizeof(float) * h_g1.size());   // the 1-spp frame
+                }
+                if (!rc) rc = aipt_frame(ctx, &cams[0], o.spp, sh.depth, o.tr_flags, f_first, d_out[0]);
+            }
             if (!rc && B == 1 && o.prefetch && !sh.gpu_lock && k + 1 < rk.f1) {     // the next frame's trace, beside this denoise
                 aipt_camera next = sh.cam0;
                 const float phi = sh.phi0 + o.pan * std::sin(2.0 * 3.14159265358979323846 * (k + 1) / 300.0);
@@ -274,7 +297,7 @@ void render(const Shared& sh, Rank& rk) {
             aipt_download(ctx, h_o.data(), d_out[j], sizeof(float) * h_o.size());
             char name[64];
             snprintf(name, sizeof(name), "/frame_%04d", k + j);
-            const auto rgb = to_image(h_g.data(), plane, stride, W, H, 3, 255.0f);
+            const auto rgb = to_image(o.spp > 1 ? h_g1.data() : h_g.data(), plane, stride, W, H, 3, 255.0f);
             const auto nrm = to_image(h_g.data() + 3 * plane, plane, stride, W, H, 3, 100.0f);
             const auto dep = to_image(h_g.data() + 6 * plane, plane, stride, W, H, 1, 10.0f);
             const auto alb = to_image(h_g.data() + 7 * plane, plane, stride, W, H, 3, 255.0f);
@@ -284,6 +307,10 @@ void render(const Shared& sh, Rank& rk) {
                       write_png(o.out_dir + "/Depth" + name + ".png", dep.data(), W, H, 1) &&
                       write_png(o.out_dir + "/Albedos" + name + ".png", alb.data(), W, H, 3) &&
                       write_png(o.out_dir + "/Denoised" + name + ".png", den.data(), W, H, 3);
+            if (o.spp > 1) {
+                const auto gt = to_image(h_g.data(), plane, stride, W, H, 3, 255.0f);       // planes 0-2 = image / spp
+                ok = ok && write_png(o.out_dir + "/GroundTruth" + name + ".png", gt.data(), W, H, 3);
+            }
             if (o.npy) {
                 // the G-buffer with its padding stripped: [10][H][W]
                 std::vector<float> g((size_t)10 * W * H);
@@ -292,6 +319,12 @@ void render(const Shared& sh, Rank& rk) {
                         memcpy(&g[((size_t)c * H + y) * W], &h_g[c * plane + (size_t)y * stride], sizeof(float) * W);
                 ok = ok && write_npy(o.out_dir + name + "_gbuffer.npy", g.data(), 10, H, W) &&
                      write_npy(o.out_dir + name + "_denoised.npy", h_o.data(), 3, H, W);
+                if (o.spp > 1) {                                   // ... and the 1-spp G-buffer the accumulation started from
+                    for (int c = 0; c < 10; c++)
+                        for (int y = 0; y < H; y++)
+                            memcpy(&g[((size_t)c * H + y) * W], &h_g1[c * plane + (size_t)y * stride], sizeof(float) * W);
+                    ok = ok && write_npy(o.out_dir + name + "_gbuffer_1spp.npy", g.data(), 10, H, W);
+                }
             }
             if (!ok) { rk.err = "cannot write frame under " + o.out_dir; return; }
         }
@@ -313,8 +346,9 @@ int main(int argc, char** argv) {
     if (argc < 2) {
         printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
                " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w]"
-               " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--sort-material] [--dump-weights FILE]"
-               " [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]\n", argv[0]);
+               " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--sort-material] [--cache-first-bounce]"
+               " [--motion-blur] [--no-cull] [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth]"
+               " [--dump-weights FILE] [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]\n", argv[0]);
         return 1;
     }
     Shared sh;
@@ -343,6 +377,14 @@ int main(int argc, char** argv) {
         else if (a == "--no-aa") o.tr_flags &= ~AIPT_TRACE_AA;
         else if (a == "--no-compaction") o.tr_flags &= ~AIPT_TRACE_COMPACT;
         else if (a == "--sort-material") o.tr_flags |= AIPT_TRACE_SORT_MATERIAL;
+        else if (a == "--cache-first-bounce") o.tr_flags |= AIPT_TRACE_CACHE_FIRST_BOUNCE;       // CACHE_BOUNCE (pathtrace.cu:22)
+        else if (a == "--motion-blur") o.tr_flags |= AIPT_TRACE_MOTION_BLUR;                     // MOTION_BLUR (pathtrace.cu:27)
+        else if (a == "--no-cull") o.tr_flags |= AIPT_TRACE_NO_CULL;                             // RAY_CULLING false (pathtrace.cu:23)
+        else if (a == "--dielectric") o.tr_flags |= AIPT_TRACE_DIELECTRIC;                       // DIELECTRIC (interactions.h:6)
+        else if (a == "--mesh-normal-view") o.tr_flags |= AIPT_TRACE_MESH_NORMAL_VIEW;           // MESH_NORMAL_VIEW (interactions.h:4)
+        else if (a == "--recompute-normals") o.recompute_normals = true;                         // RECOMPUTE_NORMALS (scene.cpp:9)
+        else if (a == "--spp") { need(1); o.spp = atoi(argv[++i]); }
+        else if (a == "--ground-truth") o.ground_truth = true;                                   // GROUND_TRUTH (main.cpp:41)
         else if (a == "--gpus") { need(1); o.gpus = atoi(argv[++i]); }
         else if (a == "--ranks") { need(1); o.ranks = atoi(argv[++i]); }
         else if (a == "--shim") o.shim = true;
@@ -375,12 +417,22 @@ int main(int argc, char** argv) {
 
     aipt_scene* scene = nullptr;
     char err[512];
-    int rc = aipt_scene_load(o.scene_path.c_str(), &scene, err, sizeof(err));
+    int rc = aipt_scene_load_ex(o.scene_path.c_str(), o.recompute_normals ? AIPT_SCENE_RECOMPUTE_NORMALS : 0u, &scene, err, sizeof(err));
     if (rc) { fprintf(stderr, "aiptd: %s\n", err); return 1; }
     if (o.res_w > 0 && o.res_h > 0) aipt_scene_set_resolution(scene, o.res_w, o.res_h);
     int ngeoms, nmats, nfaces, iterations, scene_depth;
     aipt_scene_info(scene, &ngeoms, &nmats, &nfaces, &iterations, &scene_depth);
     sh.depth = o.depth > 0 ? o.depth : scene_depth;
+    if (o.ground_truth) o.spp = iterations;                    // renderState->iterations (scene.cpp:121-122)
+    if (o.spp < 1) { fprintf(stderr, "aiptd: --spp %d\n", o.spp); return 1; }
+    if (o.spp > 1 && (o.batch > 1 || o.prefetch)) {
+        fprintf(stderr, "aiptd: --spp > 1 renders frame by frame (the batched / prefetched traces are iteration-1 only)\n");
+        return 1;
+    }
+    if ((o.tr_flags & (AIPT_TRACE_SORT_MATERIAL | AIPT_TRACE_CACHE_FIRST_BOUNCE | AIPT_TRACE_MOTION_BLUR)) && o.batch > 1) {
+        fprintf(stderr, "aiptd: --sort-material / --cache-first-bounce / --motion-blur are single-frame toggles: use --batch 1\n");
+        return 1;
+    }
     aipt_scene_camera(scene, &sh.cam0);
     aipt_scene_orbit_params(scene, &sh.zoom, &sh.phi0, &sh.theta);
     sh.W = sh.cam0.resolution[0]; sh.H = sh.cam0.resolution[1];
@@ -443,6 +495,7 @@ int main(int argc, char** argv) {
     if (!o.out_dir.empty()) {
         mkdir(o.out_dir.c_str(), 0755);
         for (const char* d : {"RGB", "Normals", "Depth", "Albedos", "Denoised"}) mkdir((o.out_dir + "/" + d).c_str(), 0755);
+        if (o.spp > 1) mkdir((o.out_dir + "/GroundTruth").c_str(), 0755);
     }
     // one host thread per rank (SURVEY 8b "Threading": one ctx per GPU, one host thread per ctx)
     const auto t0 = std::chrono::steady_clock::now();
@@ -462,9 +515,9 @@ int main(int argc, char** argv) {
         sum_t += rk.sum_t; sum_d += rk.sum_d; timed += rk.timed;
     }
     printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"depth\": %d, \"frames_per_s\": %.3f, \"ms_trace\": %.4f, "
-           "\"ms_denoise\": %.4f, \"ranks\": %d, \"gpus\": %d, \"broadcast\": \"%s\", \"batch\": %d, \"includes_file_output\": %s}\n",
+           "\"ms_denoise\": %.4f, \"ranks\": %d, \"gpus\": %d, \"broadcast\": \"%s\", \"batch\": %d, \"spp\": %d, \"includes_file_output\": %s}\n",
            o.frames, W, H, sh.depth, o.frames / (wall_ms * 1e-3), timed ? sum_t / timed : 0.0, timed ? sum_d / timed : 0.0, R, o.gpus,
-           R == 1 ? "none" : rccl ? "rccl" : "in-process shim", o.batch, o.out_dir.empty() ? "false" : "true");
+           R == 1 ? "none" : rccl ? "rccl" : "in-process shim", o.batch, o.spp, o.out_dir.empty() ? "false" : "true");
     for (Rank& rk : ranks) aipt_destroy(rk.ctx);
     aipt_scene_release(scene);
     return 0;

@@ -1174,12 +1174,25 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
             if (y < H) {                                       // wave-uniform
 #pragma unroll
                 for (int k = 0; k < 16; k++) { s1[k] += acc[r][k]; s2[k] = fmaf(acc[r][k], acc[r][k], s2[k]); }
+                if (g.d2s) {
+                    // upsample + conv as a half-resolution conv (see conv3x3_f16x3): virtual channel 4 p + c is channel c of the child
+                    // (2 y + (p >> 1), 2 x + (p & 1)) of this lane's pixel; register quad j of half gq is parity p = 2 j + gq, its fourth
+                    // value an exact zero (zero weights and bias): one C4 store per parity
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int p = 2 * j + gq;
+                        if (lane_ok)
+                            *reinterpret_cast<f32x4*>(g.out + (((size_t)(2 * y + (p >> 1)) * (2 * W)) + 2 * x + (p & 1)) * 4) =
+                                f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]};
+                    }
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const int quad = (n0 >> 2) + 2 * j + gq;
                     if (lane_ok && quad * 4 < g.cout)
                         *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) =
                             f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]};
+                }
                 }
             }
         }
@@ -1220,14 +1233,15 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
     if (g.stat) {
         if (m < 16) {
             const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
-            const int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+            int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+            if (g.d2s) cl = cl < 16 ? (cl & 3) : 31;           // a channel's four children share its sums (slot 31: the unused virtual channels, all zero)
             const BnFix fx = bn_fix((double)bsum1), fq = bn_fix((double)bsum2);
             unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
             atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
             atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
         }
         __syncthreads();
-        if (tid < 32 && n0 + tid < g.cout) {
+        if (tid < 32 && n0 + tid < (g.d2s ? g.d2s : g.cout)) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * BN_WORDS);
 #pragma unroll
             for (int k = 0; k < BN_WORDS; k++) atomicAdd(dst + k, (unsigned long long)bnacc[tid * BN_WORDS + k]);
@@ -1447,6 +1461,10 @@ struct LayerW {
     float* d_bias32 = nullptr;
     unsigned char* d_wsplit_d2s = nullptr;   // the same layout for the depth-to-space form of dec1.c1 (12 virtual outputs in one group)
     float* d_bias32_d2s = nullptr;
+    // ... and for conv3x3_f16x3r: single-accumulator scaling, virtual channel 4 * parity + j (a parity's three channels + a zero one
+    // = one register quad of a lane = one C4 store); [0]: fp32 taps, [1]: taps rounded to fp16 first (AIPT_DN_IMPL_MFMA_F16W)
+    unsigned char* d_wsplit1_d2s[2] = {nullptr, nullptr};
+    float* d_bias32_d2s4 = nullptr;
 };
 
 struct Tensor {
@@ -1536,6 +1554,7 @@ static void free_weights(DenoiseState* s) {
         hipFree(l.d_w); hipFree(l.d_w_raw); hipFree(l.d_bias); hipFree(l.d_gamma); hipFree(l.d_beta);
         hipFree(l.d_ab_running); hipFree(l.d_wsplit); hipFree(l.d_wsplit1); hipFree(l.d_wsplit1_16); hipFree(l.d_bias32);
         hipFree(l.d_w_d2s); hipFree(l.d_bias_d2s); hipFree(l.d_wsplit_d2s); hipFree(l.d_bias32_d2s);
+        hipFree(l.d_wsplit1_d2s[0]); hipFree(l.d_wsplit1_d2s[1]); hipFree(l.d_bias32_d2s4);
         l = LayerW();
     }
     s->have_weights = false;
@@ -1690,7 +1709,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, s->cur, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, s->cur, dst.p, (size_t)H * W, stat);
-    } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16) {
+    } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16 && f16_range_ok(s, batch, H / 2, W / 2, 65000.0)) {
         // upsample + conv with 3 outputs on the split-fp16 kernel: half-resolution conv, 12 virtual channels, depth-to-space store
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.a.up = 0; gh.b.up = 0;
@@ -1704,10 +1723,21 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
         gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
-        const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
-        gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
-        hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, s->cur, gh);
+        const int r_wpg = s->num_cus / 8;
+        if ((long long)gh.H * gh.W >= s->opt_r_minpix && gh.nchunks <= RR_MAXCH && r_wpg >= 1 && !(gh.H & 1) && !(gh.W & 1) && L.d_wsplit1_d2s[0] &&
+            f16_range_ok(s, batch, gh.H, gh.W, 4000.0)) {
+            // the register-staged kernel: 16 virtual channels (4 x parity + channel) in its one group of 32
+            gh.wsplit = L.d_wsplit1_d2s[w16_mode(s) ? 1 : 0]; gh.bias = L.d_bias32_d2s4;
+            gh.cout = 16;
+            gh.tiles_x = (gh.W + RR_PX - 1) / RR_PX; gh.tiles_y = (gh.H + 3) / 4; gh.groups = 1;
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<false,12,3,false,4,false>");
+            hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(8u * (unsigned)r_wpg), dim3(768), convr_lds_bytes(gh.nchunks, false), s->cur, gh);
+        } else {
+            const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
+            gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
+            snprintf(s->kname[li], sizeof(s->kname[li]), "%s", F16X3_NAME_8ROW);   // the <1,8,false,false> instantiation in both weight modes
+            hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(grid_1d(grid.x, grid.y, 1)), dim3(512), 0, s->cur, gh);
+        }
     } else if (L.d_w_d2s && upA) {
         // upsample + conv with 3 outputs -> half-resolution conv with 12 virtual channels + depth-to-space store
         g.a.up = 0; g.b.up = 0;
@@ -1923,6 +1953,27 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes) {
                 unsigned char*& dst_w = rounded ? L.d_wsplit_d2s16 : L.d_wsplit_d2s;
                 AIPT_HIP(ctx, hipMalloc((void**)&dst_w, ws.size() * 2));
                 AIPT_HIP(ctx, hipMemcpy(dst_w, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+                if (L.cout <= 3) {                                // conv3x3_f16x3r's copy (see LayerW)
+                    std::vector<_Float16> w1((size_t)nch * (WSLAB / 2), (_Float16)0.0f);
+                    for (int v = 0; v < vco; v++)
+                        for (int kc = 0; kc < nch * KH; kc++)
+                            for (int t = 0; t < 9; t++) {
+                                const float x = wf[((size_t)v * (nch * KH) + kc) * 9 + t] * WS1;
+                                const _Float16 h = (_Float16)x;
+                                const int v4 = 4 * (v / L.cout) + v % L.cout;
+                                const size_t o = (size_t)(kc / KH) * (WSLAB / 2) + ((size_t)t * 32 + v4) * KH + (kc % KH);
+                                w1[o] = h;
+                                w1[o + 9 * 32 * KH] = (_Float16)(x - (float)h);
+                            }
+                    AIPT_HIP(ctx, hipMalloc((void**)&L.d_wsplit1_d2s[rounded], w1.size() * 2));
+                    AIPT_HIP(ctx, hipMemcpy(L.d_wsplit1_d2s[rounded], w1.data(), w1.size() * 2, hipMemcpyHostToDevice));
+                }
+            }
+            if (L.cout <= 3) {
+                std::vector<float> b4(32, 0.0f);
+                for (int v = 0; v < vco; v++) b4[4 * (v / L.cout) + v % L.cout] = bv[v];
+                AIPT_HIP(ctx, hipMalloc((void**)&L.d_bias32_d2s4, 32 * 4));
+                AIPT_HIP(ctx, hipMemcpy(L.d_bias32_d2s4, b4.data(), 32 * 4, hipMemcpyHostToDevice));
             }
             std::vector<float> b32v(32, 0.0f);
             for (int v = 0; v < vco; v++) b32v[v] = bv[v];

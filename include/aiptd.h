@@ -221,8 +221,9 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);
 int aipt_denoise_configure(aipt_ctx* ctx, int height, int width);
 int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
 /* Operand range of the split-fp16 implementations (AIPT_DN_IMPL_MFMA_F16X3 / _F16W; AIPT_DN_IMPL_MFMA and _VALU are plain fp32).
- *  - network input (the G-buffer, in the caller's units): |x| <= 2^20 (1.0e6), no absolute floor that matters (2^-32); larger
- *    values saturate at 2^20.  The reference model is fp32 throughout (recurrent_autoencoder_model.py:8-142) and has no such bound.
+ *  - network input (the G-buffer, in the caller's units): held to max(2^-22 |x|, 2^-32) absolute for |x| <= 2^20 (1.0e6); larger
+ *    values saturate at 2^20, and a frame whose EVERY plane is below ~1e-3 (unit normals never are) loses relative precision.
+ *    The reference model is fp32 throughout (recurrent_autoencoder_model.py:8-142) and has neither bound.
  *  - BatchNorm sums are two-word fixed point: exact and order-independent while |sum x|, sum x^2 < 9.2e18 per channel and frame.
  *  - normalised activations y = LeakyReLU(BN(x)) are held as fp16 pairs: |y| < 4 094 on the levels of >= AIPT_DN_OPT_R_MINPIX
  *    pixels, < 65 504 below.  With AIPT_DN_BN_BATCH, |y| <= max|gamma| * sqrt(pixels) + max|beta| always holds, and a level whose

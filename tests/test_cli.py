@@ -113,3 +113,101 @@ def test_cli_batched_frames_and_gpu_count_check(tmp_path):
     n = torch.cuda.device_count()
     r = subprocess.run([CLI, scene, "--frames", "2", "--gpus", str(n + 1)], capture_output=True, text=True)
     assert r.returncode == 1 and "refusing to run on fewer" in r.stderr            # never silently fewer GPUs than asked for
+
+
+@pytest.mark.gpu
+def test_cli_ground_truth_mode_accumulates_spp_iterations(tmp_path):
+    """--spp 4 = the reference's GROUND_TRUTH loop (main.cpp:41,147-165): four iterations per camera position accumulate
+    (pathtrace.cu:400, 88-92: planes 0-2 = image / iter) before the frame is denoised and the camera advances; RGB/ holds the
+    1-spp image of iteration 1, GroundTruth/ the accumulated one (train.sh:13-27).  Against the oracle's iter 1..4 accumulation,
+    bit for bit; the denoised frame is the network on the accumulated tensor."""
+    import oracle
+    from PIL import Image
+    W, H, depth, spp = 96, 64, 3, 4
+    out = tmp_path / "gt"
+    r = subprocess.run([CLI, CORNELL, "--frames", "2", "--res", str(W), str(H), "--depth", str(depth), "--out", str(out), "--npy",
+                        "--spp", str(spp), "--hidden", "reset", "--impl", "f32", "--pan", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["spp"] == spp and info["frames"] == 2
+    sc = oracle.OracleScene.parse(CORNELL, res=(W, H), depth=depth)
+    accum = np.zeros(3 * W * H, np.float32)
+    g_ref = np.zeros((10, H, W), np.float32)
+    for it in range(1, spp + 1):
+        sc.pathtrace(iter=it, accum=accum, gbuf=g_ref)
+        if it == 1:
+            g1 = g_ref.copy()
+    for k in range(2):                                         # --pan 0: both frames see the first-frame camera
+        g = np.load(out / f"frame_{k:04d}_gbuffer.npy")
+        assert np.array_equal(g, g_ref), f"frame {k}: accumulated G-buffer differs from the oracle's {spp} iterations"
+        assert np.array_equal(np.load(out / f"frame_{k:04d}_gbuffer_1spp.npy"), g1)
+        gt = np.asarray(Image.open(out / "GroundTruth" / f"frame_{k:04d}.png")).astype(np.int32)
+        assert np.array_equal(gt, np.clip((g_ref[0:3] * 255.0).astype(np.int32), 0, 255).transpose(1, 2, 0))
+        rgb = np.asarray(Image.open(out / "RGB" / f"frame_{k:04d}.png")).astype(np.int32)
+        assert np.array_equal(rgb, np.clip((g1[0:3] * 255.0).astype(np.int32), 0, 255).transpose(1, 2, 0))
+        assert not np.array_equal(rgb, gt)
+    y = np.load(out / "frame_0001_denoised.npy")
+    y_ref = oracle.DenoiseOracle(synth.make_blob(565), 64, 96).forward(g_ref, True, False)
+    assert np.abs(y - y_ref).max() <= 1e-3
+    # --ground-truth takes the count from the scene file's ITERATIONS (scene.cpp:121-122)
+    scene = tmp_path / "cornell3.txt"
+    txt = open(CORNELL).read()
+    import re
+    assert re.search(r"^ITERATIONS\s+\d+", txt, flags=re.M)
+    scene.write_text(re.sub(r"^ITERATIONS\s+\d+", "ITERATIONS  3", txt, flags=re.M))
+    r = subprocess.run([CLI, str(scene), "--frames", "1", "--res", str(W), str(H), "--depth", str(depth), "--ground-truth"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["spp"] == 3
+    r = subprocess.run([CLI, CORNELL, "--frames", "2", "--spp", "2", "--batch", "2"], capture_output=True, text=True)
+    assert r.returncode == 1 and "frame by frame" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch,flag", [("--cache-first-bounce", "TRACE_CACHE_FIRST_BOUNCE"), ("--no-cull", "TRACE_NO_CULL"),
+                                         ("--dielectric", "TRACE_DIELECTRIC"), ("--mesh-normal-view", "TRACE_MESH_NORMAL_VIEW")])
+def test_cli_switches_for_the_reference_defines(tmp_path, switch, flag):
+    """the reference's #defines as run-time flags OF THE CLI (pathtrace.cu:22-27, interactions.h:4-6): each switch
+    reaches the trace as its AIPT_TRACE_* flag -- the G-buffer aiptd writes equals the oracle's restatement of that branch."""
+    import oracle
+    W, H, depth = 96, 64, 4
+    out = tmp_path / "o"
+    extra = ["--no-aa"] if switch == "--cache-first-bounce" else []          # the reference asserts AA off with the cache
+    r = subprocess.run([CLI, CORNELL, "--frames", "1", "--res", str(W), str(H), "--depth", str(depth), "--out", str(out), "--npy",
+                        "--impl", "f32", switch] + extra, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sc = oracle.OracleScene.parse(CORNELL, res=(W, H), depth=depth)
+    fl = (oracle.TRACE_AA | oracle.TRACE_COMPACT | getattr(oracle, flag)) & ~(oracle.TRACE_AA if extra else 0)
+    cache = np.zeros(W * H * 36, np.uint8) if switch == "--cache-first-bounce" else None
+    g_ref, _, _ = sc.pathtrace(flags=fl, cache=cache)
+    assert np.array_equal(np.load(out / "frame_0000_gbuffer.npy"), g_ref), switch
+
+
+@pytest.mark.gpu
+def test_cli_motion_blur_moves_the_primitives_every_fourth_iteration(tmp_path):
+    """--motion-blur = MOTION_BLUR true (pathtrace.cu:27, 318-331, 442-446): moveGeom with dt = 0.10 before every iteration that is a
+    multiple of 4.  A scene file whose sphere carries the reference's `VEL 0 -0.1 0` (scenes/Scenes/cornell.txt:123), 4 spp: the
+    accumulated G-buffer equals the oracle's, whose geometry moved before iteration 4, and differs from the run without the switch."""
+    import oracle
+    W, H, depth, spp = 96, 64, 3, 4
+    txt = open(CORNELL).read()
+    assert txt.rstrip().endswith("SCALE       3 3 3") and "\nsphere\n" in txt     # the last object is the ball
+    scene = tmp_path / "cornell_vel.txt"
+    scene.write_text(txt.rstrip() + "\nVEL         0 -0.1 0\n")
+    outs = {}
+    for name, extra in (("blur", ["--motion-blur"]), ("still", [])):
+        out = tmp_path / name
+        r = subprocess.run([CLI, str(scene), "--frames", "1", "--res", str(W), str(H), "--depth", str(depth), "--out", str(out), "--npy",
+                            "--spp", str(spp), "--impl", "f32"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs[name] = np.load(out / "frame_0000_gbuffer.npy")
+    sc = oracle.OracleScene.parse(str(scene), res=(W, H), depth=depth)
+    assert any(any(v != 0 for v in g.vel) for g in sc.geoms)
+    accum = np.zeros(3 * W * H, np.float32)
+    g_ref = np.zeros((10, H, W), np.float32)
+    for it in range(1, spp + 1):
+        if it % 4 == 0:
+            sc.move_geoms(0.10)
+        sc.pathtrace(iter=it, accum=accum, gbuf=g_ref)
+    assert np.array_equal(outs["blur"], g_ref)
+    assert not np.array_equal(outs["still"], g_ref)

@@ -138,6 +138,11 @@ struct ConvArgs {
     int sc;
     int d2s;             // depth-to-space store: virtual channel v = (2a+b)*d2s + j goes to out[j][2y+a][2x+b]
     int tiles_x, tiles_y, groups;   // pixel tiles and output-channel groups of the launch (1-D XCD-aware grid)
+    // conv3x3_quad<.., false>: the layer's own normalisation and the planar, cropped network output
+    BnRef out_bn;
+    float out_slope;
+    float* out_planar;   // [cout][oh][ow]
+    int oh, ow;
 };
 
 // 1-D grid -> (pixel tile, output-channel group), XCD-aware.  Workgroup b runs on XCD b % 8 (observed dispatch order;
@@ -952,7 +957,7 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
 // below 2^-29, fine for normalised activations, not for a first-hit distance in centimetres).  One chunk: the layer is bound by
 // its 158 MB, the second accumulator is free (8 waves per CU).
 template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4, bool PLANAR = false>
-__global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
+__global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const ConvArgsH g) {
     constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
     static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1250,18 +1255,39 @@ __global__ __launch_bounds__(NWV * 64) void conv3x3_f16x3r(const ConvArgsH g) {
 }
 
 // -------------------------------------------------------------------------------------------------- single-quad conv
-// dec1.c2 (3 -> 3): one C4 quad in, one out, no concat, no resampling -- 30 MB of traffic and 76 MFLOP, so it is a
-// streaming kernel: one thread per strip of 4 output pixels, the 3 x 6 input neighbourhood in registers (sixteen-byte
-// loads, neighbouring lanes overlap in L1), weights through the scalar cache, one 16-byte store per pixel.
-template <int CIN, int COUT>
+// dec1.c2 (3 -> 3) + the network's last BatchNorm / LeakyReLU + crop: one C4 quad in, three planes out, no concat, no resampling.
+// 76 MFLOP on 15 MB, so the layer is two streaming passes instead of conv -> raw tensor -> normalisation pass:
+//   STATS = true   the conv's per-channel sums only (batch statistics; nothing is stored)
+//   STATS = false  the conv again, normalised with those sums (or the running statistics) and written as the planar, cropped
+//                  network output: 15 + 15 MB read and 11 MB written instead of 15 r + 15 w, 15 r + 11 w and a third launch.
+// Both passes run the same instruction sequence on the same inputs: the values pass two normalises are the values pass one summed.
+// Mapping: lane = pixel.  A wave slides down a strip of 64 columns x QROWS rows: ONE coalesced 16-byte load per lane and input row
+// (the next row is in flight while this one is multiplied), the left / right neighbours are the same registers shifted by one
+// lane (DPP), so a wave produces the 62 inner columns.  (Round 3's form -- a thread per 4-pixel strip with its 3 x 6 neighbourhood
+// from eighteen 16-byte loads at a 64-byte lane stride -- was bound by L1 accesses: 18 us per pass for 15 MB.)
+constexpr int QROWS = 8, QCOLS = 62;
+__device__ __forceinline__ float dpp_shr1f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true)); }
+__device__ __forceinline__ float dpp_shl1f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true)); }
+template <int CIN, int COUT, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
     __shared__ float2 red[4][COUT];
-    const int tid = threadIdx.x;
-    const int H = g.H, W = g.W, W4 = (W + 3) >> 2;
-    const int strip = blockIdx.x * 256 + tid;
-    const int y = strip / W4, xs = (strip - y * W4) * 4;
-    const bool live = y < H;
-    const float4* in4 = reinterpret_cast<const float4*>(g.a.p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = g.H, W = g.W;
+    const int nsx = (W + QCOLS - 1) / QCOLS;
+    const int strip = blockIdx.x * 4 + wave;                      // wave-uniform
+    const int sy = strip / nsx, sx = strip - sy * nsx;
+    const int y0 = sy * QROWS, x = sx * QCOLS - 1 + lane;
+    const bool xin = x >= 0 && x < W;
+    const float4* col = reinterpret_cast<const float4*>(g.a.p) + min(max(x, 0), W - 1);
+    const bool live = y0 < H;                                      // wave-uniform (strips past the end: the last block's spare waves)
+    // all QROWS + 2 input rows of the strip are requested before anything else -- before the BatchNorm coefficients, whose own
+    // chain (statistics -> fp64 -> rsqrt) is a memory round trip: with one row in flight per wave a pass was a chain of
+    // QROWS + 1 dependent round trips (14 us for 15 MB)
+    float4 raw[QROWS + 2];
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < QROWS + 2; r++) raw[r] = col[(size_t)min(max(y0 - 1 + r, 0), H - 1) * W];
+    }
     float ca[CIN], cb[CIN];
 #pragma unroll
     for (int c = 0; c < CIN; c++) {
@@ -1269,61 +1295,65 @@ __global__ __launch_bounds__(256) void conv3x3_quad(const ConvArgs g) {
         ca[c] = ab.x; cb[c] = ab.y;
     }
     const float slope = g.a.slope;
-    float v[3][6][CIN];
+    float2 oab[COUT];
+    if (!STATS) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const int yy = y + r - 1;
-        const bool yin = live && yy >= 0 && yy < H;
-        const int yc = min(max(yy, 0), H - 1);
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int xx = xs + i - 1;
-            const bool in = yin && xx >= 0 && xx < W;
-            const float4 raw = in4[(size_t)yc * W + min(max(xx, 0), W - 1)];
-            const float rr[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int c = 0; c < CIN; c++) {
-                const float t = fmaf(ca[c], rr[c], cb[c]);
-                v[r][i][c] = in ? fmaxf(t, t * slope) : 0.0f;       // zero padding in the normalised domain
-            }
-        }
+        for (int j = 0; j < COUT; j++) oab[j] = bn_ab(g.out_bn, j);
     }
-    float acc[4][COUT];
+    // win[ky][kx][c]: the normalised inputs of the rows y-1, y, y+1 at columns x-1, x, x+1 (zero padding in the normalised domain)
+    float win[3][3][CIN];
+    auto put_row = [&](int slot, int yy, float4 raw) {
+        const bool in = xin && yy >= 0 && yy < H;
+        const float rr[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-    for (int p = 0; p < 4; p++)
-#pragma unroll
-        for (int j = 0; j < COUT; j++) acc[p][j] = g.bias[j];
-#pragma unroll
-    for (int j = 0; j < COUT; j++)
-#pragma unroll
-        for (int c = 0; c < CIN; c++)
-#pragma unroll
-            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const float w = g.w_raw[((size_t)j * CIN + c) * 9 + ky * 3 + kx];    // wave-uniform: scalar load
-#pragma unroll
-                    for (int p = 0; p < 4; p++) acc[p][j] = fmaf(v[ky][p + kx][c], w, acc[p][j]);
-                }
+        for (int c = 0; c < CIN; c++) {
+            const float t = fmaf(ca[c], rr[c], cb[c]);
+            const float v = in ? fmaxf(t, t * slope) : 0.0f;
+            win[slot][1][c] = v;
+            win[slot][0][c] = dpp_shr1f(v);                        // column x - 1 (lane 0: unused)
+            win[slot][2][c] = dpp_shl1f(v);                        // column x + 1 (lane 63: unused)
+        }
+    };
     float s1[COUT], s2[COUT];
 #pragma unroll
     for (int j = 0; j < COUT; j++) { s1[j] = 0.f; s2[j] = 0.f; }
-    float4* out4 = reinterpret_cast<float4*>(g.out);
+    if (live) {
+        put_row(0, y0 - 1, raw[0]);
+        put_row(1, y0, raw[1]);
+        const bool col_ok = lane >= 1 && lane <= QCOLS && x < W;
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
-        const bool ok = live && xs + p < W;
+        for (int r = 0; r < QROWS; r++) {
+            const int y = y0 + r;
+            // window slots rotate with r: row y-1 in slot r % 3, y in (r + 1) % 3, y + 1 in (r + 2) % 3
+            put_row((r + 2) % 3, y + 1, raw[r + 2]);
+            float acc[COUT];
 #pragma unroll
-        for (int j = 0; j < COUT; j++) {
-            float t = acc[p][j];
-            if (g.out_lrelu) t = lrelu(t, SLOPE);
-            o[j] = t;
-            if (ok) { s1[j] += t; s2[j] = fmaf(t, t, s2[j]); }
+            for (int j = 0; j < COUT; j++) acc[j] = g.bias[j];
+#pragma unroll
+            for (int j = 0; j < COUT; j++)
+#pragma unroll
+                for (int c = 0; c < CIN; c++)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[j] = fmaf(win[(r + ky) % 3][kx][c], g.w_raw[((size_t)j * CIN + c) * 9 + ky * 3 + kx], acc[j]);   // scalar loads
+            if (g.out_lrelu) {
+#pragma unroll
+                for (int j = 0; j < COUT; j++) acc[j] = lrelu(acc[j], SLOPE);
+            }
+            const bool ok = col_ok && y < H;
+            if (STATS) {
+#pragma unroll
+                for (int j = 0; j < COUT; j++) { const float t = ok ? acc[j] : 0.0f; s1[j] += t; s2[j] = fmaf(t, t, s2[j]); }
+            } else if (ok && y < g.oh && x < g.ow) {
+#pragma unroll
+                for (int j = 0; j < COUT; j++)
+                    g.out_planar[((size_t)j * g.oh + y) * g.ow + x] = lrelu(fmaf(oab[j].x, acc[j], oab[j].y), g.out_slope);
+            }
         }
-        if (ok) out4[(size_t)y * W + xs + p] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (g.stat) {
-        const int lane = tid & 63, wave = tid >> 6;
+    if (STATS) {
 #pragma unroll
         for (int j = 0; j < COUT; j++) {
             float a = s1[j], b = s2[j];
@@ -1513,6 +1543,7 @@ struct DenoiseState {
     long long opt_f16_minpix = 14000;  // >= : conv3x3_f16x3 with 8-row tiles, below: 4-row tiles
     long long opt_small_minpix = 0;    // <  : the f32-MFMA kernels
     int opt_fused_pool = 1;            // 2x2 pool of an encoder block's output in the conv's epilogue (0: pool2_norm launches)
+    int opt_r_waves = 12;              // waves per workgroup of conv3x3_f16x3r: 12 (a CU's whole register file) or 8 (a third left free)
     // largest |gamma| / |beta| of the loaded BatchNorms: with batch statistics |BN(x)| <= |gamma| sqrt(pixels) + |beta|, which
     // decides whether a level may run on kernels that hold normalised activations in fp16 pairs (run_conv)
     float bn_gmax = 0.0f, bn_bmax = 0.0f;
@@ -1607,6 +1638,7 @@ static DenoiseState* state(aipt_ctx* ctx) {
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1673,7 +1705,8 @@ static bool conv_fuses_pool(const DenoiseState* s, bool batch, int H, int W) {
 }
 
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
-                    int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr) {
+                    int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr,
+                    float* final_out = nullptr, int final_h = 0, int final_w = 0) {
     const LayerW& L = s->L[li];
     ConvArgs g;
     g.a = ConvSrc{A.p, A.bn, A.C, upA, A.slope, A.planar};
@@ -1751,10 +1784,16 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         else if (t.rw == 1 && t.mbx == 2) launch_mfma<1, 2, 1>(g, grid, s->cur);
         else launch_mfma<1, 1, 1>(g, grid, s->cur);
     } else if (L.cout == 3 && L.cin == 3 && !B && !upA && !g.a.planar) {
-        const int strips = ((W + 3) / 4) * H;
-        const int nblk = (strips + 255) / 256;
-        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3>");
-        hipLaunchKernelGGL((conv3x3_quad<3, 3>), dim3(nblk), dim3(256), 0, s->cur, g);
+        // the output layer: statistics pass (batch statistics only), then conv + normalisation + crop straight into the caller's planes
+        if (!final_out) return fail(ctx, AIPT_E_STATE, "layer %d: the single-quad kernel writes the network output", li);
+        const int strips = ((W + QCOLS - 1) / QCOLS) * ((H + QROWS - 1) / QROWS);      // one wave per 62 x 8 pixel strip
+        const int nblk = (strips + 3) / 4;
+        g.out_planar = final_out; g.oh = final_h; g.ow = final_w; g.out_slope = SLOPE;
+        g.out_bn = batch ? BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)}
+                         : BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};
+        snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3,false>");
+        if (batch) hipLaunchKernelGGL((conv3x3_quad<3, 3, true>), dim3(nblk), dim3(256), 0, s->cur, g);
+        hipLaunchKernelGGL((conv3x3_quad<3, 3, false>), dim3(nblk), dim3(256), 0, s->cur, g);
     } else if (impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0)) {
         // split-fp16 MFMA
         ConvArgsH gh;
@@ -1791,6 +1830,10 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else if (s->opt_r_waves == 8) {
+                snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<false,8,3,false,4,false>");
+                hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false>), dim3(pgrid), dim3(512), lds, s->cur, gh);
+            }
             else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
         } else {
             // LDS-tiled kernel.  Tile rows = waves per workgroup: 8, or 4 on the levels below opt_f16_minpix (too few 8 x 32 tiles
@@ -2116,6 +2159,9 @@ int aipt_denoise_set_option(aipt_ctx* ctx, int option, long long value) {
         case AIPT_DN_OPT_F16_MINPIX: s->opt_f16_minpix = value; break;
         case AIPT_DN_OPT_SMALL_MINPIX: s->opt_small_minpix = value; break;
         case AIPT_DN_OPT_FUSED_POOL: s->opt_fused_pool = value != 0; break;
+        case AIPT_DN_OPT_R_WAVES:
+            if (value != 8 && value != 12) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: AIPT_DN_OPT_R_WAVES is 8 or 12");
+            s->opt_r_waves = (int)value; break;
         default: return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: unknown option %d", option);
     }
     return AIPT_OK;
@@ -2236,10 +2282,13 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     for (int k = 5; k >= 1; k--) {
         const int h = H >> (k - 1), w = W >> (k - 1);
         if ((rc = run_conv(ctx, s, li++, *prev, 1, &X.P[k - 1], 1, h, w, 0, X.D1[k], batch, true))) return rc;
-        if ((rc = run_conv(ctx, s, li++, X.D1[k], 0, nullptr, 0, h, w, 0, X.D2[k], batch, false))) return rc;
+        // dec1.c2 writes the normalised, cropped network output itself (conv3x3_quad); the VALU cross-check path keeps the raw
+        // tensor + apply_norm
+        const bool last = k == 1 && s->impl != AIPT_DN_IMPL_VALU;
+        if ((rc = run_conv(ctx, s, li++, X.D1[k], 0, nullptr, 0, h, w, 0, X.D2[k], batch, false, nullptr, last ? d_out3 : nullptr, out_h, out_w))) return rc;
         prev = &X.D2[k];
     }
-    {
+    if (s->impl == AIPT_DN_IMPL_VALU) {
         const size_t n = (size_t)out_h * out_w;
         const int grid = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
         hipLaunchKernelGGL(apply_norm, dim3(grid, 1), dim3(256), 0, st, X.D2[1].p, X.D2[1].bn, SLOPE, 3, H, W,

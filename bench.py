@@ -81,6 +81,7 @@ def parse_args(argv=None):
                     help="frame by frame (--batch 1) only: trace frame k+1 while frame k is denoised, the two on disjoint halves "
                          "of the CUs (aipt_frame_prefetch; one frame of latency, same bits)")
     ap.add_argument("--trace-flags", type=int, default=None, help="AIPT_TRACE_* bits (default AA | COMPACT)")
+    ap.add_argument("--dn-opt", action="append", metavar="OPTION=VALUE", help="aipt_denoise_set_option(OPTION, VALUE): kernel-selection experiments")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
@@ -186,6 +187,9 @@ class Workload:
         ctx.frame_configure(self.W, self.H)
         self.impl = {"f16x3": api.DN_IMPL_MFMA_F16X3, "f16w": api.DN_IMPL_MFMA_F16W, "f32": api.DN_IMPL_MFMA}[args.impl]
         ctx.denoise_set_impl(self.impl)
+        for kv in (args.dn_opt or []):                         # tuning experiments: --dn-opt OPTION=VALUE (aipt_denoise_set_option)
+            k, v = kv.split("=")
+            ctx.denoise_set_option(int(k), int(v))
         self.B = max(1, args.batch if batch is None else batch)
         if self.B > 1:
             ctx.frames_configure(self.B)
@@ -332,6 +336,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run_frames(args.warmup, per_rank)
+    t_enq = time.perf_counter()                               # every launch of the timed region is queued (nothing has been waited for)
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
@@ -456,12 +461,25 @@ def main():
                 "note": (f"fp16 dense MFMA peak 2500 / {int(mfma_per_product)} MFMAs per product" if split else "f32-input MFMA peak")}
         hbm = {"achieved_GBps_algorithmic": round(gbps, 1), "peak_GBps": MI355X_HBM_BPS / 1e9,
                "frac": round(gbps * 1e9 / MI355X_HBM_BPS, 4)}
+        # HBM traffic per launch: NOT measured in this run -- rocprofv3 PMC passes of the same command, committed under profiles/
+        # (tools/collect_evidence.sh); quoted only when that run's launch mix of the kernel equals this run's
+        pm_conv = pmc_entry(conv_dominant)
+        conv_traffic = conv_traffic_src = None
+        if pm_conv:
+            lpf = pm_conv.get("launches_per_frame")
+            if lpf is not None and abs(lpf - len(prof_layers)) < 0.01:
+                conv_traffic = pm_conv.get("hbm_bytes_per_launch")
+                conv_traffic_src = (f"profiles/pmc_dominant.json @{pmc_file_sha()}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    f"this command (another run; {lpf:g} launches of the kernel per frame there as here), not measured in this run")
+            else:
+                conv_traffic_src = (f"null: profiles/pmc_dominant.json @{pmc_file_sha()} averaged {lpf} launches of this kernel per frame, "
+                                    f"this run has {len(prof_layers)}")
         conv_roof = {"bound": "hbm" if hbm_bound else "mfma",
                      "achieved": round(gbps, 1) if hbm_bound else round(tflops, 3),
                      "peak": MI355X_HBM_BPS / 1e9 if hbm_bound else round(mfma_peak, 1),
                      "unit": "GB/s" if hbm_bound else "TFLOP/s",
                      "frac": hbm["frac"] if hbm_bound else mfma["frac"],
-                     "traffic": pmc_traffic(conv_dominant),
+                     "traffic": conv_traffic, "traffic_source": conv_traffic_src,
                      "kernel": conv_dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
                      "ms_per_frame": round(avg_ms * len(prof_layers), 4),
                      "launches_timed": launches,
@@ -496,6 +514,8 @@ def main():
             traffic = pm.get("hbm_bytes_per_launch") if pm and pm.get("frames_per_launch") == fpc else None
             tr_roof = {"bound": "hbm", "achieved": round(g_late, 1), "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
                        "frac": round(g_late * 1e9 / MI355X_HBM_BPS, 5), "traffic": traffic,
+                       "traffic_source": (f"profiles/pmc_dominant.json @{pmc_file_sha()} (rocprofv3 PMC passes of another run with {fpc} "
+                                          "frames per launch), not measured in this run") if traffic is not None else None,
                        "traffic_note": (None if traffic is not None else
                                         "the committed PMC pass traced a different number of frames per launch than this run"),
                        "kernel": name, "launches_per_frame": round(len(late) / fpc, 3), "avg_launch_ms": round(t_late / len(late), 5),
@@ -550,6 +570,7 @@ def main():
             # the mode `value` is quoted in: a batch of frames is in flight together, so the first frame of a call is delivered
             # after the whole call; the interactive figures (no batching) are under "frame_by_frame"
             "latency_frames": min(B, args.steps) if B > 1 else (1 if args.prefetch else 0),
+            "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
             "frame_by_frame": {"value": round(world * fbf_fps, 3), "unit": "frames/s", "latency_frames": 0,
                                "prefetch": {"value": round(world * fbf_pf_fps, 3), "latency_frames": 1,
                                             "note": "aipt_frame_prefetch: frame k+1 traced beside the denoise of frame k on disjoint CUs"},
@@ -567,6 +588,13 @@ def main():
                                        "rank 0's own frame-by-frame render of those frames"},
             "roofline": roof,
             "roofline_other": other,
+            # the whole frame against the HBM roof north_star names: algorithmic bytes of one frame (trace byte model + every
+            # activation read and written once) over the measured time per frame of the timed region
+            "roofline_frame": {"bound": "hbm", "achieved": round((trace_bytes + dn_bytes) / (ms_per_step * 1e-3) / 1e9, 1),
+                               "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
+                               "frac": round((trace_bytes + dn_bytes) / (ms_per_step * 1e-3) / MI355X_HBM_BPS, 5),
+                               "algorithmic_bytes_per_frame": trace_bytes + dn_bytes, "ms_per_frame": round(ms_per_step, 4),
+                               "note": "no kernel of the frame is HBM-bound (DESIGN.md 5): conv = MFMA + VALU issue, bounce = VALU issue"},
             "cpu_baseline": cpu,
             "frame": {"ms_trace": round(trace_ms, 4), "ms_denoise": round(denoise_ms, 4),
                       "split_note": "one un-pipelined frame (aipt_frame) after the timed region",
@@ -589,6 +617,15 @@ def pmc_entry(kernel):
         return json.load(open(path)).get("kernels", {}).get(kernel)
     except Exception:
         return None
+
+
+def pmc_file_sha():
+    """first 12 hex digits of the sha256 of profiles/pmc_dominant.json (what a quoted traffic figure comes from)"""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "profiles", "pmc_dominant.json"), "rb").read()).hexdigest()[:12]
+    except Exception:
+        return "missing"
 
 
 def pmc_traffic(kernel):

@@ -22,7 +22,7 @@ EXPECTED = {
     "conv3x3_mfma<2,2,1>", "conv3x3_mfma<2,2,2>", "conv3x3_mfma<2,2,3>", "conv3x3_mfma<1,2,1>", "conv3x3_mfma<1,2,2>", "conv3x3_mfma<1,2,3>",
     "conv3x3_mfma<1,1,1>",
     # output layers and the on-GPU cross-check kernel
-    "conv3x3_quad<3,3>", "conv3x3_valu",
+    "conv3x3_quad<3,3,true>", "conv3x3_quad<3,3,false>", "conv3x3_valu",
 }
 
 

@@ -16,11 +16,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     blob = synth.make_blob(1)
     nctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    opts = [kv.split("=") for kv in sys.argv[3:]]              # aipt_denoise_set_option experiments: OPTION=VALUE ...
     ctxs = [api.Context(0) for _ in range(nctx)]
     xs, ys = [], []
     for c in ctxs:
         c.denoise_configure(H, W)
         c.load_weights(blob)
+        for k, v in opts:
+            c.denoise_set_option(int(k), int(v))
         xs.append(torch.from_numpy(synth.make_gbuffer(H, W, 3, 0)).cuda())
         ys.append(torch.empty(3, H, W, device="cuda"))
 

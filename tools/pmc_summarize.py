@@ -60,6 +60,10 @@ def main():
                      "the calibrated pattern, so its figure is an upper bound); WRITE_SIZE uncalibrated; averaged over all "
                      "launches of the kernel in the run (tools/pmc_summarize.py)",
            "kernels": {}}
+    # forward passes of the run = launches of the output layer's second pass (one per denoised frame): gives every conv kernel its
+    # launches per frame, which bench.py compares with the launch mix of ITS run before quoting the traffic
+    nframes = len(f.get("conv3x3_quad<3,3,false>", [])) or None
+    out["frames_denoised"] = nframes
     for k in kernels:
         if k not in f or k not in w:
             print(f"no rows for kernel {k}; have {sorted(f)}", file=sys.stderr)
@@ -68,6 +72,8 @@ def main():
         write = 1024.0 * sum(w[k]) / len(w[k])
         out["kernels"][k] = {"hbm_bytes_per_launch": fetch + write, "fetch_bytes_per_launch": fetch,
                              "write_bytes_per_launch": write, "launches_averaged": [len(f[k]), len(w[k])]}
+        if nframes and k.startswith("conv3x3"):
+            out["kernels"][k]["launches_per_frame"] = round(len(f[k]) / nframes, 4)
         if fpl and k.startswith("trace_bounce") and k.endswith(",true>"):       # the pooled (batched) instantiation
             out["kernels"][k]["frames_per_launch"] = fpl
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -28,7 +28,7 @@ SCENE_RECOMPUTE_NORMALS = 1
 TRACE_DEFAULT = TRACE_AA | TRACE_COMPACT
 DN_BN_BATCH, DN_BN_RUNNING, DN_HIDDEN_CARRY, DN_HIDDEN_RESET = 1, 0, 2, 0
 DN_IMPL_MFMA, DN_IMPL_VALU, DN_IMPL_MFMA_F16X3, DN_IMPL_MFMA_F16W = 0, 1, 2, 3
-DN_OPT_R_MINPIX, DN_OPT_F16_MINPIX, DN_OPT_SMALL_MINPIX, DN_OPT_FUSED_POOL, DN_OPT_R_WAVES = 1, 2, 3, 4, 5
+DN_OPT_R_MINPIX, DN_OPT_F16_MINPIX, DN_OPT_SMALL_MINPIX, DN_OPT_FUSED_POOL, DN_OPT_KY_SPLIT = 1, 2, 3, 4, 5
 GEOM_SPHERE, GEOM_CUBE = 0, 1
 
 

@@ -502,9 +502,9 @@ struct ConvArgsH {
     int ablate;                    // -DAIPT_CONV_ABLATE builds only (tools/conv_ablate.sh): bit mask of the parts to leave out
 };
 
-template <int RW, int NWV>
+template <int RW, int NWV, int KYS = 1>
 struct ConvCfgH {
-    static constexpr int TH = NWV * RW, TW = 32, NT = NWV * 64;
+    static constexpr int TH = NWV * RW, TW = 32, NT = NWV * KYS * 64;
     static constexpr int RS = TW + 2;
     static constexpr int PL = (TH + 2) * RS;
     static constexpr int A_BYTES = PL * PXB;                 // one of hi / lo
@@ -561,9 +561,15 @@ __device__ unsigned int g_conv_key;
 // unit instead of one 16-byte load, no separate layout pass over the input.
 // W16: fp16 conv weights (BASELINE configs[4], AIPT_DN_IMPL_MFMA_F16W): the weights are the fp16 roundings the hi half
 // of the slab already holds, so the lo half is neither staged nor multiplied (2 MFMAs per product, half the weight traffic).
-template <int RW, int NWV, bool PLANAR = false, bool W16 = false>
-__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
-    using Cfg = ConvCfgH<RW, NWV>;
+// KYS = 3 (4-row tiles of the small levels): THREE waves per tile row, one per tap row ky -- twelve waves share a chunk's staging
+// (a third of the transform work each) and run 9 MFMAs per chunk instead of 27; the three partial accumulators of a row are
+// summed through LDS once, in a fixed order, by the ky = 0 wave, which also runs the epilogue.  The launches of the small levels
+// have fewer workgroups than the chip has CUs and last as long as ONE workgroup's chain of chunk steps: this
+// shortens the step.
+template <int RW, int NWV, bool PLANAR = false, bool W16 = false, int KYS = 1>
+__global__ __launch_bounds__(NWV * KYS * 64, KYS == 3 ? 3 : NWV == 8 ? 4 : 2) void conv3x3_f16x3(const ConvArgsH g) {
+    static_assert(KYS == 1 || (KYS == 3 && RW == 1), "tap-row split: one row per wave");
+    using Cfg = ConvCfgH<RW, NWV, KYS>;
     constexpr int NT = Cfg::NT, TPQ = Cfg::TPQ;
     constexpr int WP = W16 ? WSLAB / 32 : WSLAB / 16;          // 16-byte weight pieces of a chunk that are staged
     constexpr int TH = Cfg::TH, RS = Cfg::RS, PL = Cfg::PL, NU = Cfg::NU, NWP = Cfg::NWP;
@@ -574,7 +580,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     float* tab_a = reinterpret_cast<float*>(smem + 2 * Cfg::A_BYTES + 2 * Cfg::B_BYTES);   // BN scale per K16 channel
     float* tab_b = tab_a + Cfg::MAXC;                                                       // BN shift
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = KYS == 1 ? tid >> 6 : (tid >> 6) % NWV;      // the tile row of this wave
+    const int kyg = KYS == 1 ? 0 : (tid >> 6) / NWV;              // KYS = 3: its tap row
+    const bool primary = kyg == 0;                                // runs the epilogue
     const TileId tile = tile_of_block(g.tiles_x, g.tiles_y, g.groups);
     if (!tile.valid) return;
     CPH_INIT();
@@ -625,17 +634,23 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #pragma unroll
     for (int r = 0; r < RW; r++)
 #pragma unroll
-        for (int k = 0; k < 16; k++) { acc0[r][k] = PLANAR ? bj * XSP : bj; acc1[r][k] = 0.f; }
+        for (int k = 0; k < 16; k++) { acc0[r][k] = !primary ? 0.f : PLANAR ? bj * XSP : bj; acc1[r][k] = 0.f; }
 
-    f32x4 pa[NU];
-    u32x4 pw[NWP];
+    // register sets of prefetched chunks: ONE chunk ahead.  (Two ahead with KYS = 3 -- a set is 16 registers there -- measured no
+    // faster, 17.0 vs 16.3 us on enc5.l1: the chunk step is not waiting for memory.)
+    constexpr int PFD = 1;
+    f32x4 pa_sets[PFD][NU];
+    u32x4 pw_sets[PFD][NWP];
 #ifdef AIPT_CONV_ABLATE
 #pragma unroll
-    for (int j = 0; j < NU; j++) pa[j] = f32x4{0.5f, 0.25f, 0.125f, 1.0f};
+    for (int u = 0; u < PFD; u++) {
 #pragma unroll
-    for (int j = 0; j < NWP; j++) pw[j] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        for (int j = 0; j < NU; j++) pa_sets[u][j] = f32x4{0.5f, 0.25f, 0.125f, 1.0f};
+#pragma unroll
+        for (int j = 0; j < NWP; j++) pw_sets[u][j] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+    }
 #endif
-    auto fetch = [&](int chunk) {
+    auto fetch = [&](int chunk, f32x4 (&pa)[NU], u32x4 (&pw)[NWP]) {
         const bool fa = chunk < ca16;
         const int cl = fa ? chunk : chunk - ca16;                         // chunk inside its source
         const ConvSrc& s = fa ? g.a : g.b;
@@ -666,7 +681,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 pw[j] = *reinterpret_cast<const u32x4*>(wsrc + j * NT * 16);
         }
     };
-    auto stash = [&](int chunk) {
+    auto stash = [&](int chunk, const f32x4 (&pa)[NU], const u32x4 (&pw)[NWP]) {
         if (abl & 8) return;
         const float slope = chunk < ca16 ? g.a.slope : g.b.slope;
         const f32x4 ca = *reinterpret_cast<const f32x4*>(tab_a + chunk * KH + q * 4);
@@ -697,7 +712,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     };
 
     CPH(0);
-    fetch(0);
+    fetch(0, pa_sets[0], pw_sets[0]);
+    if (PFD == 2 && g.nchunks > 1) fetch(1, pa_sets[PFD - 1], pw_sets[PFD - 1]);
     CPH(1);
     CPH_WAITVM();
     CPH(10);
@@ -721,14 +737,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     CPH(12);
     __syncthreads();                                           // tables and the zeroed halo visible
     CPH(2);
-    for (int chunk = 0; chunk < g.nchunks; chunk++) {
+    for (int chunk0 = 0; chunk0 < g.nchunks; chunk0 += PFD) {
+#pragma unroll
+    for (int u = 0; u < PFD; u++) {
+        const int chunk = chunk0 + u;
+        if (chunk >= g.nchunks) break;                             // (workgroup-uniform)
         CPH_WAITVM();
         CPH(3);
-        stash(chunk);
+        stash(chunk, pa_sets[u], pw_sets[u]);
         CPH(4);
         if (!(abl & 128)) __syncthreads();
         CPH(5);
-        if (chunk + 1 < g.nchunks) fetch(chunk + 1);
+        if (chunk + PFD < g.nchunks) fetch(chunk + PFD, pa_sets[u], pw_sets[u]);
         CPH(6);
         if (!(abl & 1)) {
 #pragma unroll
@@ -736,27 +756,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
             f16x8 fah[RW + 2], fal[RW + 2];
 #pragma unroll
             for (int hr = 0; hr < RW + 2; hr++) {
-                const int off = ((wave * RW + hr) * RS + li + kx) * PXB + lg * 16;
+                if (KYS == 3 && hr != 0) continue;                   // (KYS = 3: slot 0 holds this wave's one halo row, wave + kyg)
+                const int off = ((wave * RW + hr + (KYS == 3 ? kyg : 0)) * RS + li + kx) * PXB + lg * 16;
                 fah[hr] = *reinterpret_cast<const f16x8*>(Ahi + off);
                 fal[hr] = *reinterpret_cast<const f16x8*>(Alo + off);
             }
 #pragma unroll
-            for (int ky = 0; ky < 3; ky++) {
+            for (int kyi = 0; kyi < (KYS == 3 ? 1 : 3); kyi++) {
+                const int ky = KYS == 3 ? kyg : kyi;
                 const int boff = ((ky * 3 + kx) * 32 + li) * PXB + lg * 16;
                 const f16x8 fbh = *reinterpret_cast<const f16x8*>(Bhi + boff);
                 const f16x8 fbl = *reinterpret_cast<const f16x8*>(Bhi + Cfg::B_BYTES + boff);
 #ifdef AIPT_CONV_ABLATE
                 if (abl & 64) {                                  // fragments read (and kept alive), nothing multiplied
 #pragma unroll
-                    for (int r = 0; r < RW; r++) asm volatile("" :: "v"(fah[r + ky]), "v"(fal[r + ky]), "v"(fbh), "v"(fbl));
+                    for (int r = 0; r < RW; r++) asm volatile("" :: "v"(fah[KYS == 3 ? 0 : r + kyi]), "v"(fal[KYS == 3 ? 0 : r + kyi]), "v"(fbh), "v"(fbl));
                     continue;
                 }
 #endif
 #pragma unroll
                 for (int r = 0; r < RW; r++) {
-                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbh, acc0[r], 0, 0, 0);
-                    if (!W16) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[r + ky], fbl, acc1[r], 0, 0, 0);
-                    acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[r + ky], fbh, acc1[r], 0, 0, 0);
+                    const int fr = KYS == 3 ? 0 : r + kyi;
+                    acc0[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[fr], fbh, acc0[r], 0, 0, 0);
+                    if (!W16) acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[fr], fbl, acc1[r], 0, 0, 0);
+                    acc1[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[fr], fbh, acc1[r], 0, 0, 0);
                 }
             }
         }
@@ -764,6 +787,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
         CPH(7);
         if (!(abl & 128)) __syncthreads();
         CPH(8);
+    }
     }
 
     // ---- epilogue.  D fragment (32x32): register k of lane l = pixel (k&3) + 8*(k>>2) + 4*(l>>5), channel l&31.
@@ -773,16 +797,36 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     const bool quad_ok = (j & ~3) < g.cout;
     const bool interior = ty0 + TH <= H && tx0 + 32 <= W;     // block-uniform
     float s1 = 0.f, s2 = 0.f;
+    // KYS = 3: the tap rows' partial sums meet in LDS (behind the slots the epilogue uses; the loop's last barrier has passed):
+    // [ky - 1][row][register][lane], added by the ky = 0 wave in the order ky = 0, 1, 2 whatever the waves' timing was
+    float* kred = reinterpret_cast<float*>(smem) + 3072;
+    static_assert(KYS == 1 || 3072 * 4 + (KYS - 1) * NWV * 1024 * 4 <= (int)sizeof(smem), "tap-row partial sums must fit the staging area");
+    if (KYS == 3) {
+        if (!primary) {
+            const f32x16 t = acc0[0] + acc1[0] * (1.0f / 2048.0f);
+#pragma unroll
+            for (int k = 0; k < 16; k++) kred[(((kyg - 1) * NWV + wave) * 16 + k) * 64 + lane] = t[k];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int r = 0; r < RW; r++) {
         const int y = ty0 + wave * RW + r;
         f32x16 t = acc0[r] + acc1[r] * (1.0f / 2048.0f);
+        if (KYS == 3 && primary) {
+#pragma unroll
+            for (int kk = 1; kk < KYS; kk++)
+#pragma unroll
+                for (int k = 0; k < 16; k++) t[k] += kred[(((kk - 1) * NWV + wave) * 16 + k) * 64 + lane];
+        }
         if (PLANAR) t = t * (1.0f / XSP);
         if (g.out_lrelu) {
 #pragma unroll
             for (int k = 0; k < 16; k++) t[k] = fmaxf(t[k], t[k] * SLOPE);
         }
-        if (interior) {
+        if (!primary) {
+            // (tap-row helpers: nothing to sum or store; they still meet the barriers below)
+        } else if (interior) {
 #pragma unroll
             for (int k = 0; k < 16; k++) { s1 += t[k]; s2 = fmaf(t[k], t[k], s2); }
         } else {
@@ -802,12 +846,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
 #pragma unroll
             for (int m = 0; m < 8; m++) hv[m] = pos ? fmaxf(t[2 * m], t[2 * m + 1]) : fminf(t[2 * m], t[2 * m + 1]);
             float* pbuf = reinterpret_cast<float*>(smem) + 1024 + wave * 8 * 64;
-            if (wave & 1) {
+            if ((wave & 1) && primary) {
 #pragma unroll
                 for (int m = 0; m < 8; m++) pbuf[m * 64 + lane] = hv[m];
             }
             __syncthreads();
-            if (!(wave & 1)) {
+            if (!(wave & 1) && primary) {
                 const float* qbuf = pbuf + 8 * 64;                  // the odd wave below
 #pragma unroll
                 for (int m = 0; m < 8; m++) {
@@ -828,6 +872,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
                 }
             }
         }
+        if (!primary) continue;
         if (g.d2s) {
             // upsample+conv as a half-resolution conv: the 4 * d2s (<= 16) virtual channels of a pixel are the d2s real
             // channels of its four full-resolution children.  Through LDS (this wave's own 2 KB; the loop's last barrier
@@ -863,7 +908,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void conv3x3_f16x3(cons
     if (g.stat && !(abl & 32)) {
         float2* red = reinterpret_cast<float2*>(smem);         // [NWV waves][32]; the last loop barrier already passed
         s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        if (lg == 0) red[wave * 32 + li] = make_float2(s1, s2);
+        if (lg == 0 && primary) red[wave * 32 + li] = make_float2(s1, s2);
         __syncthreads();
         if (tid < 32) {
             const int jj = n0 + tid;
@@ -1543,7 +1588,7 @@ struct DenoiseState {
     long long opt_f16_minpix = 14000;  // >= : conv3x3_f16x3 with 8-row tiles, below: 4-row tiles
     long long opt_small_minpix = 0;    // <  : the f32-MFMA kernels
     int opt_fused_pool = 1;            // 2x2 pool of an encoder block's output in the conv's epilogue (0: pool2_norm launches)
-    int opt_r_waves = 12;              // waves per workgroup of conv3x3_f16x3r: 12 (a CU's whole register file) or 8 (a third left free)
+    int opt_ky_split = 1;              // 4-row tiles of conv3x3_f16x3 with three waves per row (one per tap row)
     // largest |gamma| / |beta| of the loaded BatchNorms: with batch statistics |BN(x)| <= |gamma| sqrt(pixels) + |beta|, which
     // decides whether a level may run on kernels that hold normalised activations in fp16 pairs (run_conv)
     float bn_gmax = 0.0f, bn_bmax = 0.0f;
@@ -1638,7 +1683,6 @@ static DenoiseState* state(aipt_ctx* ctx) {
         // conv3x3_f16x3r declares its LDS at launch: all weight chunks of a channel group + tables
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 12, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<false, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x3r<true, 8, 3, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
@@ -1647,10 +1691,10 @@ static DenoiseState* state(aipt_ctx* ctx) {
 
 // The name rocprofv3 reports for a conv3x3_f16x3<1, rows, planar, w16> instantiation, without blanks: bench.py and
 // tools/pmc_summarize.py match kernel rows of profiles/ on it, so every launch site takes it from here.
-static void f16x3_name(char* dst, size_t n, int rows, bool planar, bool w16) {
-    snprintf(dst, n, "conv3x3_f16x3<1,%d,%s,%s>", rows, planar ? "true" : "false", w16 ? "true" : "false");
+static void f16x3_name(char* dst, size_t n, int rows, bool planar, bool w16, int kys) {
+    snprintf(dst, n, "conv3x3_f16x3<1,%d,%s,%s,%d>", rows, planar ? "true" : "false", w16 ? "true" : "false", kys);
 }
-#define F16X3_NAME_8ROW "conv3x3_f16x3<1,8,false,false>"
+#define F16X3_NAME_8ROW "conv3x3_f16x3<1,8,false,false,1>"
 
 template <int RW, int MBX, int NBB>
 static void launch_mfma(ConvArgs a, dim3 grid, hipStream_t st) {
@@ -1830,10 +1874,6 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            else if (s->opt_r_waves == 8) {
-                snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<false,8,3,false,4,false>");
-                hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false>), dim3(pgrid), dim3(512), lds, s->cur, gh);
-            }
             else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
         } else {
             // LDS-tiled kernel.  Tile rows = waves per workgroup: 8, or 4 on the levels below opt_f16_minpix (too few 8 x 32 tiles
@@ -1842,12 +1882,15 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
             gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
             const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);
-            f16x3_name(s->kname[li], sizeof(s->kname[li]), rows, gh.a.planar != 0, w16);
+            const int kys = rows == 4 && s->opt_ky_split ? 3 : 1;      // 4-row tiles: three waves per row, one per tap row
+            f16x3_name(s->kname[li], sizeof(s->kname[li]), rows, gh.a.planar != 0, w16, kys);
             if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
             else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
             else if (w16 && rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8, false, true>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else if (w16 && kys == 3) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true, 3>), dim3(nb1), dim3(768), 0, s->cur, gh);
             else if (w16) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, true>), dim3(nb1), dim3(256), 0, s->cur, gh);
             else if (rows == 8) hipLaunchKernelGGL((conv3x3_f16x3<1, 8>), dim3(nb1), dim3(512), 0, s->cur, gh);
+            else if (kys == 3) hipLaunchKernelGGL((conv3x3_f16x3<1, 4, false, false, 3>), dim3(nb1), dim3(768), 0, s->cur, gh);
             else hipLaunchKernelGGL((conv3x3_f16x3<1, 4>), dim3(nb1), dim3(256), 0, s->cur, gh);
         }
     } else {
@@ -2159,9 +2202,7 @@ int aipt_denoise_set_option(aipt_ctx* ctx, int option, long long value) {
         case AIPT_DN_OPT_F16_MINPIX: s->opt_f16_minpix = value; break;
         case AIPT_DN_OPT_SMALL_MINPIX: s->opt_small_minpix = value; break;
         case AIPT_DN_OPT_FUSED_POOL: s->opt_fused_pool = value != 0; break;
-        case AIPT_DN_OPT_R_WAVES:
-            if (value != 8 && value != 12) return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: AIPT_DN_OPT_R_WAVES is 8 or 12");
-            s->opt_r_waves = (int)value; break;
+        case AIPT_DN_OPT_KY_SPLIT: s->opt_ky_split = value != 0; break;
         default: return fail(ctx, AIPT_E_INVALID, "aipt_denoise_set_option: unknown option %d", option);
     }
     return AIPT_OK;

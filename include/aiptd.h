@@ -237,8 +237,7 @@ int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
 #define AIPT_DN_OPT_F16_MINPIX   2   /* below R_MINPIX: conv3x3_f16x3 LDS-tiled, 8-row tiles from value pixels up, 4-row below (14000) */
 #define AIPT_DN_OPT_SMALL_MINPIX 3   /* levels below value pixels: the exact f32 MFMA kernel (default 0: none) */
 #define AIPT_DN_OPT_FUSED_POOL   4   /* 1 (default): MaxPool2d(2) in the producing conv's epilogue; 0: a pool launch per encoder level */
-#define AIPT_DN_OPT_R_WAVES       5   /* waves per workgroup of conv3x3_f16x3r: 12 (default) or 8 (leaves a third of a CU's registers to
-                                        another stream's small-level workgroups) */
+#define AIPT_DN_OPT_KY_SPLIT      5   /* 1 (default): the 4-row tiles of conv3x3_f16x3 run three waves per row, one per tap row; 0: one */
 int aipt_denoise_set_option(aipt_ctx* ctx, int option, long long value);
 /* forward: d_in10 float[10][H][W] -> d_out3 float[3][H][W] */
 int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags);

@@ -22,6 +22,8 @@ R = "conv3x3_f16x3r<false,12,3,false,4,false>"
 R_PLANAR = "conv3x3_f16x3r<false,8,3,false,4,true>"
 R16 = "conv3x3_f16x3r<true,12,3,false,4,false>"
 R16_PLANAR = "conv3x3_f16x3r<true,8,3,false,4,true>"
+DEFAULTS = {api.DN_OPT_R_MINPIX: 200000, api.DN_OPT_F16_MINPIX: 14000, api.DN_OPT_SMALL_MINPIX: 0, api.DN_OPT_FUSED_POOL: 1,
+            api.DN_OPT_KY_SPLIT: 1}
 SEEN = set()          # every kernel name a passing case of this module ran (checked last, against the shipped set)
 
 
@@ -37,7 +39,7 @@ def _run(ctx, blob, frames, H, W, bn_batch=True, carry=True, impl=api.DN_IMPL_MF
     ctx.load_weights(blob)
     ctx.denoise_configure(H, W)
     ctx.denoise_set_impl(impl)
-    defaults = {api.DN_OPT_R_MINPIX: 200000, api.DN_OPT_F16_MINPIX: 14000, api.DN_OPT_SMALL_MINPIX: 0, api.DN_OPT_FUSED_POOL: 1}
+    defaults = dict(DEFAULTS)
     defaults.update(opts or {})
     for k, v in defaults.items():
         ctx.denoise_set_option(k, v)
@@ -50,8 +52,7 @@ def _run(ctx, blob, frames, H, W, bn_batch=True, carry=True, impl=api.DN_IMPL_MF
         outs.append(y.cpu().numpy())
     names = [ctx.layer_info(l)["kernel"] for l in range(28)]
     for k in defaults:                                     # leave the module-scoped context at the library's defaults
-        ctx.denoise_set_option(k, {api.DN_OPT_R_MINPIX: 200000, api.DN_OPT_F16_MINPIX: 14000, api.DN_OPT_SMALL_MINPIX: 0,
-                                   api.DN_OPT_FUSED_POOL: 1}[k])
+        ctx.denoise_set_option(k, DEFAULTS[k])
     return outs, names
 
 
@@ -175,6 +176,8 @@ def test_register_staged_kernel_with_fp16_weights(ctx):
     ({api.DN_OPT_F16_MINPIX: 0}, api.DN_IMPL_MFMA_F16X3),                       # 8-row LDS tiles on every level
     ({api.DN_OPT_F16_MINPIX: 10**9}, api.DN_IMPL_MFMA_F16X3),                   # 4-row tiles everywhere (network input through a C4 copy)
     ({api.DN_OPT_F16_MINPIX: 10**9}, api.DN_IMPL_MFMA_F16W),
+    ({api.DN_OPT_F16_MINPIX: 10**9, api.DN_OPT_KY_SPLIT: 0}, api.DN_IMPL_MFMA_F16X3),   # ... with one wave per row
+    ({api.DN_OPT_F16_MINPIX: 10**9, api.DN_OPT_KY_SPLIT: 0}, api.DN_IMPL_MFMA_F16W),
     ({api.DN_OPT_SMALL_MINPIX: 2000}, api.DN_IMPL_MFMA_F16X3),                  # the deep levels on the exact f32 MFMA kernel
     ({api.DN_OPT_FUSED_POOL: 0}, api.DN_IMPL_MFMA_F16X3),                       # pool2_norm launches
     ({}, api.DN_IMPL_MFMA),

@@ -16,8 +16,10 @@ EXPECTED = {
     "conv3x3_f16x3r<false,12,3,false,4,false>", "conv3x3_f16x3r<true,12,3,false,4,false>",
     "conv3x3_f16x3r<false,8,3,false,4,true>", "conv3x3_f16x3r<true,8,3,false,4,true>",
     # LDS-tiled split-fp16 kernel: 8-row and 4-row tiles, planar input, fp16 weights
-    "conv3x3_f16x3<1,8,false,false>", "conv3x3_f16x3<1,8,false,true>", "conv3x3_f16x3<1,8,true,false>", "conv3x3_f16x3<1,8,true,true>",
-    "conv3x3_f16x3<1,4,false,false>", "conv3x3_f16x3<1,4,false,true>",
+    "conv3x3_f16x3<1,8,false,false,1>", "conv3x3_f16x3<1,8,false,true,1>", "conv3x3_f16x3<1,8,true,false,1>", "conv3x3_f16x3<1,8,true,true,1>",
+    "conv3x3_f16x3<1,4,false,false,1>", "conv3x3_f16x3<1,4,false,true,1>",
+    # ... 4-row tiles with three waves per row, one per tap row (the default of the small levels)
+    "conv3x3_f16x3<1,4,false,false,3>", "conv3x3_f16x3<1,4,false,true,3>",
     # exact f32 MFMA kernel (AIPT_DN_IMPL_MFMA, and the fallback of levels beyond the fp16 operand range)
     "conv3x3_mfma<2,2,1>", "conv3x3_mfma<2,2,2>", "conv3x3_mfma<2,2,3>", "conv3x3_mfma<1,2,1>", "conv3x3_mfma<1,2,2>", "conv3x3_mfma<1,2,3>",
     "conv3x3_mfma<1,1,1>",

@@ -21,7 +21,7 @@ pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_su
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 python tools/pmc_summarize.py --frames-per-launch 16 --out $O/pmc_dominant.json $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv \
     'trace_bounce<false,true,true>' 'trace_bounce<true,true,false>' 'trace_bounce<false,true,false>' 'conv3x3_f16x3r<false,12,3,false,4,false>' 'conv3x3_f16x3r<false,8,3,false,4,true>' \
-    'conv3x3_f16x3<1,8,false,false>' 'conv3x3_f16x3<1,8,true,false>' 'conv3x3_f16x3<1,4,false,false>'
+    'conv3x3_f16x3<1,8,false,false,1>' 'conv3x3_f16x3<1,4,false,false,3>' 'conv3x3_quad<3,3,false>' 'conv3x3_quad<3,3,true>'
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel trace_bounce --json $O/pmc_trace.json > /dev/null
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel 'conv3x3_f16x3' --json $O/pmc_conv.json > /dev/null
 # the bench lines read roofline.traffic from profiles/pmc_dominant.json: the fresh one

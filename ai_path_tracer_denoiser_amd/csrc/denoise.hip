@@ -1878,7 +1878,12 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         } else {
             // LDS-tiled kernel.  Tile rows = waves per workgroup: 8, or 4 on the levels below opt_f16_minpix (too few 8 x 32 tiles
             // for 256 CUs); the planar input always on 8-row tiles
-            const int rows = ((long long)H * W >= s->opt_f16_minpix || gh.a.planar) ? 8 : 4;
+            // ... and, with the tap-row split (12 waves per 4-row workgroup, one workgroup per CU), on any level whose 4-row tiles
+            // all fit the chip at once: the launch then lasts one workgroup's chain of chunk steps, which the split shortens
+            // (dec4.c1 28 -> 23 us; enc4.* with 345 workgroups would need two rounds: 8-row tiles stay)
+            const long long wg4 = (long long)((W + 31) / 32) * ((H + 3) / 4) * (L.coutp32 / 32);
+            const bool one_round4 = s->opt_ky_split && wg4 <= s->num_cus;
+            const int rows = gh.a.planar ? 8 : ((long long)H * W >= s->opt_f16_minpix && !one_round4) ? 8 : 4;
             const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
             gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
             const unsigned nb1 = grid_1d(grid.x, grid.y, grid.z);

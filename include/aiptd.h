@@ -234,7 +234,8 @@ int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
  * computes the same function to <= 1e-3 and is covered by tests/test_gpu_denoise_kernels.py).  No environment variable changes
  * which arithmetic a caller gets. */
 #define AIPT_DN_OPT_R_MINPIX     1   /* levels of >= value pixels: conv3x3_f16x3r, persistent register-staged (default 200000) */
-#define AIPT_DN_OPT_F16_MINPIX   2   /* below R_MINPIX: conv3x3_f16x3 LDS-tiled, 8-row tiles from value pixels up, 4-row below (14000) */
+#define AIPT_DN_OPT_F16_MINPIX   2   /* below R_MINPIX: conv3x3_f16x3 LDS-tiled, 8-row tiles from value pixels up, 4-row below (14000) --
+                                        and 4-row on any level whose 4-row workgroups fit the chip at once (with KY_SPLIT) */
 #define AIPT_DN_OPT_SMALL_MINPIX 3   /* levels below value pixels: the exact f32 MFMA kernel (default 0: none) */
 #define AIPT_DN_OPT_FUSED_POOL   4   /* 1 (default): MaxPool2d(2) in the producing conv's epilogue; 0: a pool launch per encoder level */
 #define AIPT_DN_OPT_KY_SPLIT      5   /* 1 (default): the 4-row tiles of conv3x3_f16x3 run three waves per row, one per tap row; 0: one */

@@ -28,7 +28,7 @@
 // ranks' GPUs with RCCL (aipt_comm_*), nothing is exchanged per frame.  --ranks R > N puts several ranks on a GPU and
 // replaces RCCL by an in-process copy shim, so a one-GPU box can check that sharded rendering is byte-identical
 // (tests/test_cli.py); --reset-every C makes a single rank drop the hidden state where R ranks would (every C frames).
-// --batch B (<= 32) traces B consecutive frames with one set of launches per 16 and pipelines their denoiser passes over two
+// --batch B (<= 32) traces B consecutive frames with one set of launches per up to 24 and pipelines their denoiser passes over two
 // streams (aipt_frames; identical results).  --prefetch (frame by frame, every rank on its own GPU): the next frame's trace
 // runs beside this frame's denoise on disjoint halves of the CUs (aipt_frame_prefetch; identical results).
 #include <cmath>

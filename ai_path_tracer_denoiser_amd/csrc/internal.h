@@ -21,7 +21,7 @@ struct DenoiseState;   // denoise.hip
 // frames of one recurrent sequence whose denoiser passes are in flight together (independent sequences: 2 streams 1.25x, 3 streams 1.38x,
 // 4 streams 1.37x the throughput of one, tools/overlap_probe.py; ONE sequence, level by level behind each other: 3 in flight = 2 in flight)
 constexpr int AIPT_DN_PIPE = 2;
-constexpr int AIPT_TRACE_BATCH_MAX = 16;    // frames one set of trace launches can hold (= BMAX of trace.hip)
+constexpr int AIPT_TRACE_BATCH_MAX = 24;    // frames one set of trace launches can hold (= BMAX of trace.hip)
 constexpr int AIPT_FRAMES_MAX = 32;         // frames one aipt_frames call can hold
 
 struct aipt_ctx {

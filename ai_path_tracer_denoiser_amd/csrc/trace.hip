@@ -47,7 +47,7 @@ struct alignas(16) DevFaceP { DevFace f; int pad; };   // 80 bytes: five 16-byte
 static_assert(sizeof(DevFaceP) == 80, "DevFaceP");
 
 constexpr int MAX_DEPTH = 64;
-constexpr int BMAX = 16;       // most frames one batched trace (aipt_trace_batch) can hold
+constexpr int BMAX = 24;       // most frames one batched trace (aipt_trace_batch) can hold
 
 struct TraceState {
     DevGeom* d_geoms = nullptr; int ngeoms = 0;

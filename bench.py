@@ -14,7 +14,7 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
 Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds 32
-consecutive frames.  Their traces share one set of bounce launches per 16 frames (a single 1280x720 frame leaves most of the
+consecutive frames.  Their traces share one set of bounce launches per up to 24 frames (a single 1280x720 frame leaves most of the
 chip idle in its later bounces; the frames are interleaved pixel by pixel and a workgroup pools the BVH walks of 1024 paths,
 refilling idle lanes).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
 it, so the many small launches of one frame's deep levels run beside the full-size layers of the other; the hidden state is
@@ -563,7 +563,7 @@ def main():
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
                        "pipelining": ((f"throughput mode: a call holds up to {B} consecutive frames; their traces share launches (at most "
-                                       f"16 frames per launch set) and their denoiser passes run on two streams, frame n+1 one encoder "
+                                       f"24 frames per launch set) and their denoiser passes run on two streams, frame n+1 one encoder "
                                        f"level behind frame n (aipt_frames)" if B > 1 else
                                       "frame by frame" + ("; the next frame's trace runs beside this frame's denoise on disjoint CUs" if args.prefetch else ""))
                                       + "; frames bit-identical to un-pipelined rendering")},

@@ -172,7 +172,7 @@ int aipt_trace_configure(aipt_ctx* ctx, int width, int height);
  * (pathtrace.cu:81-94, 295-304, 379-387).  Every in-frame element is written each call; padding is left untouched. */
 int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t flags,
                float* d_gbuf, int gbuf_rows, int gbuf_stride);
-/* Batched trace (no reference equivalent; the frame sequence is the data-parallel axis): nframes <= batch <= 16
+/* Batched trace (no reference equivalent; the frame sequence is the data-parallel axis): nframes <= batch <= 24
  * iteration-1 frames with their own cameras are traced by ONE set of bounce launches -- a single 1280x720 frame leaves most of
  * the chip idle in the later bounces.  Frame f writes the G-buffer at d_gbuf + f * gbuf_frame_floats.  Every frame's
  * result is bit-identical to its own aipt_trace (the RNG index of a path is its rank among the live paths of ITS frame).  The
@@ -279,7 +279,7 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
  * for every stream of the context; work queued on the context's stream after aipt_frame sees its result. */
 int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint32_t trace_flags);
 /* Frame batches: aipt_frames_configure(batch <= 32) after aipt_frame_configure; aipt_frames traces nframes consecutive frames
- * with one set of launches per 16 frames (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the
+ * with one set of launches per up to 24 frames (32 frames: 16 + 16) (aipt_trace_batch) and then denoises them in order -- frame 0 with dn_flags_first, the
  * others with dn_flags_rest (e.g. carry the hidden state inside the batch) -- into d_out3[0..nframes).  The denoiser passes of
  * consecutive frames run on two streams, frame n+1 entering an encoder level when frame n has left it (its hidden state of
  * that level is written); everything is joined on the context's stream before the call returns.  Same results, bit for bit,

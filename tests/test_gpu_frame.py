@@ -130,15 +130,16 @@ def _mesh_scene(res, depth, ntri=4096):
 @pytest.mark.parametrize("mesh", [True, False])
 def test_batched_trace_equals_single_frame_traces(mesh):
     """aipt_trace_batch: frames traced by one set of launches are bit-identical to their own aipt_trace -- G-buffer, live counts
-    per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame).  1 to 16 frames per launch set
-    (16 = the per-frame counters, kernel-argument cameras and the 17-workgroup trace_scan at their limit), on the mesh scene
+    per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame).  1 to 24 frames per launch set
+    (24 = AIPT_TRACE_BATCH_MAX: the per-frame counters, kernel-argument cameras and the 25-workgroup trace_scan at their limit;
+    20 = what the driver's `bench.py --steps 20` traces in one call), on the mesh scene
     (pooled walks from 4 frames on) and on the primitives-only scene."""
     import torch
     W, H, depth = 100, 60, 6               # 6000 pixels per frame: the frames straddle workgroups and waves
     sc, mats, faces, box = _mesh_scene((W, H), depth)
     if not mesh:
         faces, box = faces[:0], None
-    cams = [sc.orbit(phi=sc.phi + 0.15 * k) for k in range(16)]
+    cams = [sc.orbit(phi=sc.phi + 0.15 * k) for k in range(24)]
     fl = api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0
     ctx = api.Context(0)
     ctx.pathtrace_init(sc.geoms, mats, faces, box, W, H)
@@ -149,10 +150,12 @@ def test_batched_trace_equals_single_frame_traces(mesh):
         ctx.pathtrace(c, 1, depth, g1, fl)
         ctx.sync()
         singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy(), ctx.first_hit_materials(W * H).copy()))
-    ctx.trace_configure_batch(W, H, 16)              # AIPT_TRACE_BATCH_MAX: what bench.py's 32-frame calls trace at a time
-    gb = torch.zeros(16, 10, H, W, device="cuda")
+    with pytest.raises(api.AiptError):
+        ctx.trace_configure_batch(W, H, 25)
+    ctx.trace_configure_batch(W, H, 24)              # AIPT_TRACE_BATCH_MAX
+    gb = torch.zeros(24, 10, H, W, device="cuda")
     torch.cuda.synchronize()
-    for nf in (16, 13, 9, 5, 3, 1):
+    for nf in (24, 20, 16, 13, 9, 5, 3, 1):
         gb.zero_()
         torch.cuda.synchronize()
         ctx.pathtrace_batch(cams[:nf], 1, depth, gb, fl)

@@ -375,9 +375,9 @@ int aipt_frames_prefetch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, in
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frames_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     const int back = ctx->bfront ^ 1;
-    // On the context's stream, behind the denoiser passes already queued: bounce kernels that run BESIDE conv3x3_f16x3
-    // workgroups return wrong values for runs of up to 16 consecutive lanes in a few per cent of the frames (DESIGN.md,
-    // "Known issue"; tools/concurrency_probe.py), so the library never overlaps the two.  The call still moves the trace
+    // On the context's stream, behind the denoiser passes already queued: a batch's bounce launches fill the chip, and beside the
+    // persistent conv3x3_f16x3r launches (which need every CU whole) the two starve each other -- 625 vs 797 frames/s with the
+    // trace on a low-priority side stream (tools/experiments/README.md, round 4).  The call still moves the trace
     // ahead of the host's next aipt_frames and keeps the double buffer.
     const int rc = trace_frames(ctx, ctx->stream, cams, nframes, iter, depth, trace_flags, ctx->d_gbatches[back]);
     if (rc) return rc;

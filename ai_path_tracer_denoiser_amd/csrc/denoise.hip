@@ -2248,8 +2248,8 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     pipelined = pipelined && ctx->ev_fork && !on;
     auto stream_of = [&](int set) { return set == 0 ? ctx->stream : ctx->pipe[set - 1]; };
     hipStream_t st = on ? on : pipelined ? stream_of(a) : ctx->stream;     // on: the CU-masked denoiser stream of aipt_frame
-    // conv kernels never run beside a bounce kernel on the same CUs (DESIGN.md "Known issue"): unless this pass runs on the
-    // CU-masked denoiser stream, it starts after the last trace, whichever stream that ran on
+    // the pass reads the G-buffer the last trace wrote: unless it runs on the CU-masked denoiser stream of aipt_frame_prefetch
+    // (which orders itself behind ITS trace), it starts after the last trace, whichever stream that ran on
     if (ctx->last_trace_stream && ctx->last_trace_stream != st && st != ctx->st_dn)
         AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
     s->cur = st;

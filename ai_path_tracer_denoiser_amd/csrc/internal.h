@@ -41,8 +41,8 @@ struct aipt_ctx {
     float* d_gbufs[2] = {nullptr, nullptr};
     int front = 0;
     // aipt_frame_prefetch: the next frame's trace runs on `st_trace` into the back G-buffer while this frame is denoised on
-    // `st_dn` -- two streams restricted to DISJOINT sets of CUs (hipExtStreamCreateWithCUMask): a bounce kernel and a conv kernel
-    // must never share a CU (DESIGN.md "Known issue"), and a single frame's trace does not fill the chip anyway
+    // `st_dn` -- two streams restricted to DISJOINT sets of CUs (hipExtStreamCreateWithCUMask): a scheduling choice (a single
+    // frame's trace does not fill the chip; sharing all CUs measured slower), no longer a correctness fence
     hipStream_t st_trace = nullptr, st_dn = nullptr;
     // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
     // pipelined): AIPT_DN_PIPE frames in flight

@@ -776,12 +776,11 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     static_assert((MESH && !FIRST) || !POOL, "the pool holds the mesh walks of the later bounces (bounce 0: coherent camera rays)");
     __shared__ int s_wave[4];
     __shared__ int s_pool_n, s_head;
-    // Cameras of the frames traced together.  They arrive as kernel arguments and are read from the kernel-argument segment
-    // with SCALAR loads only (wave-uniform index), then indexed per lane from this LDS copy.  `p.cams[fr]` with a per-lane
-    // frame index compiles to VECTOR loads from the kernel-argument segment (global_load_dwordx4 from kernarg + fr * 84), and
-    // those returned another launch's camera for the last lanes of a wave whenever a conv kernel shared the CU: the runtime
-    // rewrites the same kernel-argument addresses for every launch and nothing keeps the CU's vector L1 coherent with that
-    // (DESIGN.md "Root cause of the round-2 co-residency issue", tools/coresidency/kernarg_vload.hip).
+    // Cameras of the frames traced together.  They arrive as kernel arguments, are read from the kernel-argument segment with
+    // scalar loads (wave-uniform index) and indexed per lane from this LDS copy: `p.cams[fr]` with a per-lane frame index would
+    // compile to vector loads from the kernel-argument segment, 21 dwords per lane through L1 instead of one LDS read each.
+    // (Round 2 suspected those vector loads of the co-residency corruption; round 3 found packed-fp32 instructions beside gapped
+    // fp16 MFMAs to be the cause, DESIGN.md 5 -- the LDS copy stays as the cheaper access, not as a fence.)
     __shared__ aipt_camera s_cams[FIRST ? BMAX : 1];
     // dynamic LDS: [MESH: STACK_LDS x 256 stack words][POOL: pool, results][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)],
     // sized by the launch

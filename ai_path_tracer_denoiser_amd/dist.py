@@ -109,7 +109,11 @@ def checksum64(t) -> int:
     modulo 2^64: the value does not depend on the order a reduction adds in."""
     import torch
     bits = t.contiguous().view(torch.int32).flatten().to(torch.int64) & 0xFFFFFFFF
-    w = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+    # weight of position i: an odd 64-bit multiplicative hash of i (Knuth's golden-ratio constant, arithmetic modulo 2^64) -- not
+    # periodic in i, so two elements swapped or a block shifted anywhere in the frame changes the sum (ADVICE r3: the earlier
+    # (i mod 65521) + 1 missed exchanges between positions congruent modulo 65521)
+    i = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64)
+    w = ((i + 1) * -7046029254386353131) | 1                 # 0x9E3779B97F4A7C15 as int64; int64 products wrap modulo 2^64
     return int((bits * w).sum().item())
 
 

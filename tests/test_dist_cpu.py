@@ -131,3 +131,8 @@ def test_checksum64_is_position_sensitive_and_order_free():
     b[0, 0], b[0, 1] = a[0, 1], a[0, 0]                         # same multiset of values, different positions
     assert adist.checksum64(a) == adist.checksum64(a.clone()) != adist.checksum64(b)
     assert adist.checksum64(torch.tensor([0.0])) != adist.checksum64(torch.tensor([-0.0]))    # bit patterns, not values
+    # not periodic in the position: an exchange between positions 65521 apart (the period of the round-3 weights) is seen
+    t = torch.arange(200000, dtype=torch.float32)
+    u = t.clone()
+    u[5], u[5 + 65521] = t[5 + 65521], t[5]
+    assert adist.checksum64(t) != adist.checksum64(u)

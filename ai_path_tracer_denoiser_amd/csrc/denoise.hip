@@ -1105,6 +1105,17 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
     __syncthreads();
 
     const int hh = H >> 1, hw = W >> 1;
+    // Output through buffer descriptors: a store's address is (descriptor, per-lane byte offset, SCALAR byte offset) -- the row /
+    // channel-quad part is scalar arithmetic and the lanes that must not store carry an offset past the descriptor's size (the
+    // hardware drops the store): no 64-bit vector address arithmetic and no exec-mask branches per store (150 VALU instructions
+    // and 50 branches per item in the pointer form).  Tensors are allocated in whole 16-channel chunks, so a group's pad quads
+    // inside the allocation are stored too (exact zeros: zero weights and bias), whole quad pairs past it skipped by a scalar test.
+    const unsigned aq = (unsigned)((g.d2s ? 4 : g.cout) + 15) / 16u * 4u;                // allocated channel quads of the output
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(g.d2s ? 4u * (unsigned)(H * W) * 16u : aq * (unsigned)(H * W) * 16u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t pool_rs = __builtin_amdgcn_make_buffer_rsrc(g.pool_out ? g.pool_out : g.out, 0, (int)(aq * (unsigned)(hh * hw) * 16u), 0x00020000);
+    constexpr unsigned NO_STORE = 0x80000000u;                                           // + any scalar offset: past every descriptor (< 2 GiB, host-checked)
+    const int q0 = n0 >> 2;
+    typedef unsigned u4s __attribute__((ext_vector_type(4)));
     for (; it < nitems; it += stride) {
         const int rb = it / tiles_x, tx = it - rb * tiles_x;
         const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
@@ -1227,22 +1238,21 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                 if (g.d2s) {
                     // upsample + conv as a half-resolution conv (see conv3x3_f16x3): virtual channel 4 p + c is channel c of the child
                     // (2 y + (p >> 1), 2 x + (p & 1)) of this lane's pixel; register quad j of half gq is parity p = 2 j + gq, its fourth
-                    // value an exact zero (zero weights and bias): one C4 store per parity
+                    // value an exact zero (zero weights and bias): one C4 store per parity.  Lane part: child column 2 x + gq;
+                    // scalar part: child row 2 y + j
+                    const unsigned voff = lane_ok ? (unsigned)(2 * x + gq) * 16u : NO_STORE;
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int p = 2 * j + gq;
-                        if (lane_ok)
-                            *reinterpret_cast<f32x4*>(g.out + (((size_t)(2 * y + (p >> 1)) * (2 * W)) + 2 * x + (p & 1)) * 4) =
-                                f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]};
-                    }
+                    for (int j = 0; j < 2; j++)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
+                                                               out_rs, voff, (unsigned)((2 * y + j) * (2 * W)) * 16u, 0);
                 } else {
+                    const unsigned voff = lane_ok ? (unsigned)x * 16u + (gq ? (unsigned)(H * W) * 16u : 0u) : NO_STORE;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int quad = (n0 >> 2) + 2 * j + gq;
-                    if (lane_ok && quad * 4 < g.cout)
-                        *reinterpret_cast<f32x4*>(g.out + (((size_t)quad * H + y) * W + x) * 4) =
-                            f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]};
-                }
+                    for (int j = 0; j < 4; j++) {
+                        if ((unsigned)(q0 + 2 * j) >= aq) continue;      // (scalar) the whole quad pair lies past the allocation
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
+                                                               out_rs, voff, (unsigned)((q0 + 2 * j) * H + y) * (unsigned)W * 16u, 0);
+                    }
                 }
             }
         }
@@ -1252,21 +1262,23 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
 #pragma unroll
             for (int rp = 0; rp < RR_ROWS / 2; rp++) {
                 const int y = y0 + 2 * rp;
+                // max where gamma >= 0, min where gamma < 0, as ONE instruction per pair: med3(a, b, +inf) = max(a, b),
+                // med3(a, b, -inf) = min(a, b) (selecting between a computed max and a computed min cost three)
                 float pv[16];
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
-                    const bool pos = (posmask >> k) & 1u;
-                    const float v = pos ? fmaxf(acc[2 * rp][k], acc[2 * rp + 1][k]) : fminf(acc[2 * rp][k], acc[2 * rp + 1][k]);
+                    const float lim = ((posmask >> k) & 1u) ? INFINITY : -INFINITY;
+                    const float v = __builtin_amdgcn_fmed3f(acc[2 * rp][k], acc[2 * rp + 1][k], lim);
                     const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
-                    pv[k] = pos ? fmaxf(v, o) : fminf(v, o);
+                    pv[k] = __builtin_amdgcn_fmed3f(v, o, lim);
                 }
                 if (y < H) {
+                    const unsigned voff = ((m & 1) && m < RR_PX && x < W) ? (unsigned)(x >> 1) * 16u + (gq ? (unsigned)(hh * hw) * 16u : 0u) : NO_STORE;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const int quad = (n0 >> 2) + 2 * j + gq;
-                        if ((m & 1) && m < RR_PX && x < W && quad * 4 < g.cout)
-                            *reinterpret_cast<f32x4*>(g.pool_out + (((size_t)quad * hh + (y >> 1)) * hw + (x >> 1)) * 4) =
-                                f32x4{pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]};
+                        if ((unsigned)(q0 + 2 * j) >= aq) continue;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]}),
+                                                               pool_rs, voff, (unsigned)((q0 + 2 * j) * hh + (y >> 1)) * (unsigned)hw * 16u, 0);
                     }
                 }
             }
@@ -1802,6 +1814,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
         const int r_wpg = s->num_cus / 8;
         if ((long long)gh.H * gh.W >= s->opt_r_minpix && gh.nchunks <= RR_MAXCH && r_wpg >= 1 && !(gh.H & 1) && !(gh.W & 1) && L.d_wsplit1_d2s[0] &&
+            (long long)H * W * 16 < (1ll << 31) &&
             f16_range_ok(s, batch, gh.H, gh.W, 4000.0)) {
             // the register-staged kernel: 16 virtual channels (4 x parity + channel) in its one group of 32
             gh.wsplit = L.d_wsplit1_d2s[w16_mode(s) ? 1 : 0]; gh.bias = L.d_bias32_d2s4;
@@ -1862,6 +1875,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         // LDS and the normalised activations provably fit its operand range (f16_range_ok)
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
         if ((long long)H * W >= s->opt_r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && !(H & 1) && !(W & 1) &&
+            (long long)pad16(L.cout) * H * W * 4 < (1ll << 31) &&      // its output descriptors address the tensor with 31-bit offsets
             (gh.a.planar || f16_range_ok(s, batch, H, W, 4000.0))) {
             // planar input: the wide-range two-accumulator arithmetic on the hi + 2^11 lo slabs (see the kernel)
             gh.wsplit = gh.a.planar ? L.d_wsplit : w16 ? L.d_wsplit1_16 : L.d_wsplit1;

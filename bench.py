@@ -82,6 +82,7 @@ def parse_args(argv=None):
                          "of the CUs (aipt_frame_prefetch; one frame of latency, same bits)")
     ap.add_argument("--trace-flags", type=int, default=None, help="AIPT_TRACE_* bits (default AA | COMPACT)")
     ap.add_argument("--dn-opt", action="append", metavar="OPTION=VALUE", help="aipt_denoise_set_option(OPTION, VALUE): kernel-selection experiments")
+    ap.add_argument("--gate-ms", type=float, default=0.0, help="diagnostic: queue the timed region behind a spin of this many ms (profiler timelines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
@@ -334,6 +335,12 @@ def main():
         # batched: every trace call of the timed region is recorded; frame by frame: every 4th
         ctx.trace_profile_begin(nrec if B == 1 else len(timed_trace_calls), PROF_EVERY if B == 1 else 1)
     barrier()
+    if args.gate_ms > 0:
+        # diagnostic (rocprofv3 timelines): the timed call queues up behind a spin on the context's stream, so that the GPU starts it
+        # with every launch already enqueued -- under the profiler the host needs ~0.85 ms per frame to enqueue (0.12 ms without)
+        # and the streams would otherwise run host-bound.  `value` of such a run includes the spin: not a benchmark figure.
+        with torch.cuda.stream(wl.stream):
+            torch.cuda._sleep(int(args.gate_ms * 1e-3 * 2.1e9))
     t0 = time.perf_counter()
     run_frames(args.warmup, per_rank)
     t_enq = time.perf_counter()                               # every launch of the timed region is queued (nothing has been waited for)

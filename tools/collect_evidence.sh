@@ -38,9 +38,17 @@ $B --no-cpu-baseline --impl f32 --steps 32 > $O/bench_f32exact.json 2>/dev/null
 $B --no-cpu-baseline --trace-flags 35 --batch 1 --steps 30 > $O/bench_sort_material.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -o k -- $B --no-cpu-baseline > $O/kstats.log 2>&1
 AIPT_DN_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_one_stream -o k -- $B --no-cpu-baseline > $O/kstats_one_stream.log 2>&1
-# round 3: what the dominant conv kernel's time is made of (ablation build), VALU beside MFMA on one SIMD, hidden-state drift
-AIPT_F16R_MINPIX=100000000 ABLATE_MASKS="0 1 64 2 4 6 8 16 32 128 7 9 15 17 25 31 63 319 512" tools/conv_ablate.sh run > $O/conv_ablate.txt 2>&1
-[ -x tools/ubench/valu_mfma ] && tools/ubench/valu_mfma > $O/ubench_valu_mfma.txt 2>&1
+# round 4: the driver's own command first (what BENCH_rNN.json reproduces), 300-frame pans of configs[1] / [2] (BASELINE.json),
+# the drift study ON the register-staged kernel, the two-stream timeline with the call queued behind a spin
+$B --steps 20 --warmup 5 > $O/bench_driver_command.json 2>/dev/null
+$B --steps 300 --warmup 32 --no-cpu-baseline > $O/bench_config2_300frames.json 2>/dev/null
+$B --config 1 --steps 300 --warmup 32 --no-cpu-baseline > $O/bench_config1_300frames.json 2>/dev/null
+python tools/drift_probe.py 384 640 16 565 > $O/drift_384x640_default_selection.json 2>/dev/null
+python tools/drift_probe.py 192 320 32 565 0 > $O/drift_192x320_r_minpix0.json 2>/dev/null
+python tools/drift_probe.py 192 320 32 7 0 > $O/drift_192x320_r_minpix0_seed7.json 2>/dev/null
+rocprofv3 --kernel-trace --output-format csv -d $O/timeline -o k -- $B --no-cpu-baseline --no-roofline-events --steps 20 --warmup 5 --gate-ms 60 > $O/timeline.log 2>&1
+python tools/timeline_summary.py $O/timeline/k_kernel_trace.csv > $O/timeline_two_streams.txt 2>&1
+rm -rf $O/timeline
 find $O -name "*_kernel_stats.csv" | head; ls $O
 # keep the merge small: raw counter CSVs stay on the box
 rm -rf $O/pmc_*/ 

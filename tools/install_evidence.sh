@@ -10,5 +10,6 @@ cp $(find $E/kstats_one_stream -name "*kernel_stats.csv" | head -1) profiles/${R
 cp $E/pmc_dominant.json profiles/pmc_dominant.json
 cp $E/pmc_trace.json profiles/${R}_pmc_trace.json
 cp $E/pmc_conv.json profiles/${R}_pmc_conv.json
-for f in conv_ablate.txt ubench_valu_mfma.txt; do [ -f $E/$f ] && cp $E/$f profiles/${R}_$f; done
+for f in conv_ablate.txt ubench_valu_mfma.txt timeline_two_streams.txt; do [ -f $E/$f ] && cp $E/$f profiles/${R}_$f; done
+for f in $E/drift_*.json; do [ -f $f ] && cp $f profiles/${R}_$(basename $f); done
 ls profiles | grep "^${R}_"

@@ -625,12 +625,94 @@ __device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur
     }
 }
 
-__device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot) {
+// Cooperative leaf step of the pooled walk.  The lanes of a wave that hold a leaf (>= POOL_LEAF of them, 3.4 triangles each on the
+// atrium) list their (ray, triangle) pairs in LDS and ALL 64 lanes test one pair each per round: the owner's ray comes over by
+// lane permutes, the result goes to the owner's slot by a 64-bit LDS atomicMin on (t bits, face index) -- the reference's
+// "first strictly smaller t wins, ties to the lowest face index" as an order-independent minimum (t > 0: IEEE bit patterns
+// order like the values; a face index is unique, so the lane whose key equals the slot afterwards is THE winner and records its
+// leaf slot).  Same arithmetic per triangle as walk_leaf (triHitT_flat on the same operands), so the hit is bit-identical; a leaf
+// step costs ~170 instructions per 64 pairs on full lanes instead of ~150 per two triangles per lane on the ~14 lanes that hold a
+// leaf, for as many iterations as the fullest leaf needs (35 % of the walk's instructions, tools/trace_stats.py).
+#ifndef AIPT_POOL_COOP_LEAF
+#define AIPT_POOL_COOP_LEAF 1
+#endif
+constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
+struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float4* rays; };   // this wave's LDS slices
+// inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)
+__device__ __forceinline__ int wave_incl_scan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
+    return x;
+}
+__device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, WalkStack& st, int& cur, const CoopLeaf& cl, int lane) {
+    const bool at_leaf = cur < 0 && cur != WALK_DONE;
+    const int v = -cur - 1, first = v >> 3, cnt = at_leaf ? (v & 7) : 0;
+    const int incl = wave_incl_scan(cnt);                      // inclusive prefix of the triangle counts over the wave
+    const int total = __builtin_amdgcn_readlane(incl, 63), excl = incl - cnt;
+    // (no face yet: index 0 -- the bound is a primitive's hit or FLT_MAX, and a face at exactly that distance must NOT replace
+    // it (strict t_min > t in the reference's loop): its key (t, f >= 0) is never below (t, 0))
+    const unsigned long long mine = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
+    if (at_leaf) {
+        cl.best[lane] = mine;
+        cl.rays[2 * lane] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);          // the owners' rays: two 16-byte reads per tester
+        cl.rays[2 * lane + 1] = make_float4(r.d.y, r.d.z, 0.0f, 0.0f);
+        for (int k = 0; k < cnt; k++) cl.pairs[excl + k] = ((unsigned)lane << 26) | (unsigned)(first + k);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int base = 0; base < total; base += 64) {             // (wave-uniform trip count)
+        const int pi = base + lane;
+        const bool work = pi < total;
+        const unsigned pr = cl.pairs[work ? pi : 0];
+        const int owner = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
+        const float4 ra = cl.rays[2 * owner], rb = cl.rays[2 * owner + 1];
+        const v3 o = V(ra.x, ra.y, ra.z), d = V(ra.w, rb.x, rb.y);
+        unsigned long long key = ~0ull;
+        if (work) {
+            const uint4* tr = tris + (unsigned)slot * 3u;
+            const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
+            const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
+                                          V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
+                                          V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), o, d);
+            if (ta > 0.0f) {
+                key = ((unsigned long long)__float_as_uint(ta) << 32) | (unsigned)r2.y;
+                atomicMin(&cl.best[owner], key);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (key != ~0ull && cl.best[owner] == key) cl.slot[owner] = slot;      // the (so far) nearest face of that ray: its leaf slot
+        STAT_ADD(2, work ? 1 : 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (at_leaf) {
+        const unsigned long long b = cl.best[lane];
+        if (b != mine) {                                       // a face of this leaf is nearer (or as near with a lower index)
+            r.t_min = __uint_as_float((unsigned)(b >> 32));
+            r.best_face = (int)(unsigned)b;
+            r.best_slot = cl.slot[lane];
+        }
+        STAT_ADD(4, 1);
+        cur = st.sp ? st.pop() : WALK_DONE;
+    }
+    STAT_WAVE(3);
+}
+
+__device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot,
+                                             const CoopLeaf& cl, int lane, bool walk) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
     const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
     WalkRay r;
     r.start(o, d, t_min);
-    int cur = 0;
+    int cur = walk ? 0 : WALK_DONE;                            // (lanes whose ray misses the mesh box help with the leaf steps)
     st.sp = 0;
 #ifdef AIPT_TRACE_STATS
     int my_visits = 0;
@@ -638,6 +720,19 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
 #else
 #define STAT_MINE() do {} while (0)
 #endif
+    if (AIPT_POOL_COOP_LEAF) {
+        // wave-level "while-while": every lane descends to its next leaf, then ALL 64 lanes share the leaves' triangle tests
+        while (true) {
+            while (__ballot(cur >= 0)) {
+                if (cur >= 0) {
+                    STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
+                    walk_node(nodes, r, st, cur);
+                }
+            }
+            if (!__ballot(cur != WALK_DONE)) break;
+            coop_leaf_step(tris, r, st, cur, cl, lane);
+        }
+    } else {
     while (true) {
         while (cur >= 0) {
             STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
@@ -647,6 +742,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
         walk_leaf(tris, r, cur);
         cur = st.sp ? st.pop() : WALK_DONE;
         if (cur == WALK_DONE) break;
+    }
     }
     t_min = r.t_min;
     best_slot = r.best_slot;
@@ -711,85 +807,6 @@ __device__ __forceinline__ int pool_blocks(int n) {                 // 256-path 
     const int k = n / (256 * 512);                                  // keep >= 512 workgroups
     return k < 1 ? 1 : k > POOL_BLOCKS ? POOL_BLOCKS : k;
 }
-// Cooperative leaf step of the pooled walk.  The lanes of a wave that hold a leaf (>= POOL_LEAF of them, 3.4 triangles each on the
-// atrium) list their (ray, triangle) pairs in LDS and ALL 64 lanes test one pair each per round: the owner's ray comes over by
-// lane permutes, the result goes to the owner's slot by a 64-bit LDS atomicMin on (t bits, face index) -- the reference's
-// "first strictly smaller t wins, ties to the lowest face index" as an order-independent minimum (t > 0: IEEE bit patterns
-// order like the values; a face index is unique, so the lane whose key equals the slot afterwards is THE winner and records its
-// leaf slot).  Same arithmetic per triangle as walk_leaf (triHitT_flat on the same operands), so the hit is bit-identical; a leaf
-// step costs ~170 instructions per 64 pairs on full lanes instead of ~150 per two triangles per lane on the ~14 lanes that hold a
-// leaf, for as many iterations as the fullest leaf needs (35 % of the walk's instructions, tools/trace_stats.py).
-#ifndef AIPT_POOL_COOP_LEAF
-#define AIPT_POOL_COOP_LEAF 1
-#endif
-constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
-struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float4* rays; };   // this wave's LDS slices
-// inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)
-__device__ __forceinline__ int wave_incl_scan(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);     // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);     // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);     // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);     // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
-    return x;
-}
-__device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, WalkStack& st, int& cur, const CoopLeaf& cl, int lane) {
-    const bool at_leaf = cur < 0 && cur != WALK_DONE;
-    const int v = -cur - 1, first = v >> 3, cnt = at_leaf ? (v & 7) : 0;
-    const int incl = wave_incl_scan(cnt);                      // inclusive prefix of the triangle counts over the wave
-    const int total = __builtin_amdgcn_readlane(incl, 63), excl = incl - cnt;
-    const unsigned long long mine = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)r.best_face;   // (-1 -> 0xffffffff: loses to any face)
-    if (at_leaf) {
-        cl.best[lane] = mine;
-        cl.rays[2 * lane] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);          // the owners' rays: two 16-byte reads per tester
-        cl.rays[2 * lane + 1] = make_float4(r.d.y, r.d.z, 0.0f, 0.0f);
-        for (int k = 0; k < cnt; k++) cl.pairs[excl + k] = ((unsigned)lane << 26) | (unsigned)(first + k);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int base = 0; base < total; base += 64) {             // (wave-uniform trip count)
-        const int pi = base + lane;
-        const bool work = pi < total;
-        const unsigned pr = cl.pairs[work ? pi : 0];
-        const int owner = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
-        const float4 ra = cl.rays[2 * owner], rb = cl.rays[2 * owner + 1];
-        const v3 o = V(ra.x, ra.y, ra.z), d = V(ra.w, rb.x, rb.y);
-        unsigned long long key = ~0ull;
-        if (work) {
-            const uint4* tr = tris + (unsigned)slot * 3u;
-            const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
-            const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                          V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
-                                          V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), o, d);
-            if (ta > 0.0f) {
-                key = ((unsigned long long)__float_as_uint(ta) << 32) | (unsigned)r2.y;
-                atomicMin(&cl.best[owner], key);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (key != ~0ull && cl.best[owner] == key) cl.slot[owner] = slot;      // the (so far) nearest face of that ray: its leaf slot
-        STAT_ADD(2, work ? 1 : 0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (at_leaf) {
-        const unsigned long long b = cl.best[lane];
-        if (b != mine) {                                       // a face of this leaf is nearer (or as near with a lower index)
-            r.t_min = __uint_as_float((unsigned)(b >> 32));
-            r.best_face = (int)(unsigned)b;
-            r.best_slot = cl.slot[lane];
-        }
-        STAT_ADD(4, 1);
-        cur = st.sp ? st.pop() : WALK_DONE;
-    }
-    STAT_WAVE(3);
-}
-
 __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int2* s_res,
                                           WalkStack& st, int lane, const CoopLeaf& cl) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
@@ -912,6 +929,13 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     PHASE(0);
 
     const bool walk_mesh = MESH && !(FIRST && p.cache_mode == 2) && p.nfaces && !(p.flags & 0x40000000u);
+    // LDS of the cooperative leaf step (coop_leaf_step): per wave, the (ray, triangle) pair list, the rays and the result slots
+    __shared__ unsigned s_pairs[MESH && AIPT_POOL_COOP_LEAF ? 4 * COOP_PAIRS : 1];
+    __shared__ unsigned long long s_best[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
+    __shared__ int s_slot[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
+    __shared__ float4 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 512 : 1];
+    const CoopLeaf cl{s_pairs + (MESH && AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
+                      s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 128 : 0)};
     if (POOL) {
         // ---- list the paths of this workgroup's blocks that enter the mesh box, walk them all, leave (t, leaf slot) per path
         for (int j = 0; j < K; j++) {
@@ -932,12 +956,6 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
         __syncthreads();
         WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0};
-        __shared__ unsigned s_pairs[POOL && AIPT_POOL_COOP_LEAF ? 4 * COOP_PAIRS : 1];
-        __shared__ unsigned long long s_best[POOL && AIPT_POOL_COOP_LEAF ? 256 : 1];
-        __shared__ int s_slot[POOL && AIPT_POOL_COOP_LEAF ? 256 : 1];
-        __shared__ float4 s_rays[POOL && AIPT_POOL_COOP_LEAF ? 512 : 1];
-        const CoopLeaf cl{s_pairs + (AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
-                          s_slot + (AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (AIPT_POOL_COOP_LEAF ? wave * 128 : 0)};
         pool_walk(p, s_pool, s_pool_n, &s_head, s_res, st, lane, cl);
         __syncthreads();
         PHASE(2);
@@ -971,8 +989,14 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     }
 
     bool alive_after = false;
+    // (per-path state lives across the two halves of the path's work: between them the whole wave, dead lanes included, meets in
+    // the un-pooled BVH walk, whose leaf steps are shared by all 64 lanes)
+    v3 o = V(0, 0, 0), d = V(1, 1, 1), col = V(0, 0, 0);
+    float t_min = FLT_MAX;
+    int materialid = -1;
+    v3 hitP = V(0, 0, 0), normal = V(0, 0, 0);
+    bool want_walk = false;
     if (alive) {
-        v3 o, d, col;
         if (FIRST) {                                                             // generateRayFromCamera :155-182
             camera_ray(p, s_cams[FIRST ? fr : 0], pix, o, d);
             col = V(1.0f, 1.0f, 1.0f);
@@ -985,9 +1009,6 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
 
         // ---- computeIntersections :200-306 (primitives first, then the mesh; strict t_min > t keeps the first of equals)
-        float t_min = FLT_MAX;
-        int materialid = -1;
-        v3 hitP = V(0, 0, 0), normal = V(0, 0, 0);
         const bool from_cache = FIRST && p.cache_mode == 2;        // CACHE_BOUNCE, iter > 1 (pathtrace.cu:473-476)
         if (from_cache) {
             const float* c = p.cache + i;
@@ -1062,20 +1083,23 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
                     const float t = triangleTest(p.faces[fi], o, d, tp, tn);
                     if (t > 0.0f && t_min > t) { t_min = t; materialid = p.faces[fi].materialid; hitP = tp; normal = tn; }
                 }
-            } else {
-                int best_slot = -1;
-                WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0};
-                bvh4_nearest(p, o, d, st, t_min, best_slot);
-                if (best_slot >= 0) {
-                    // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
-                    DevFace f;
-                    load_leaf_face(p, best_slot, f);
-                    v3 tp, tn;
-                    const float t = triangleTest(f, o, d, tp, tn);
-                    t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
-                }
-            }
+            } else want_walk = true;
         }
+    }
+    if (MESH && !POOL && __syncthreads_or(want_walk)) {           // (workgroup-uniform: the cooperative leaf step's LDS slices are per wave)
+        int best_slot = -1;
+        WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0};
+        bvh4_nearest(p, o, d, st, t_min, best_slot, cl, lane, want_walk);
+        if (best_slot >= 0) {
+            // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
+            DevFace f;
+            load_leaf_face(p, best_slot, f);
+            v3 tp, tn;
+            const float tt = triangleTest(f, o, d, tp, tn);
+            t_min = tt; materialid = f.materialid; hitP = tp; normal = tn;
+        }
+    }
+    if (alive) {
         PHASE(2);
         const bool hit = materialid != -1;
         if (FIRST && p.cache_mode == 1) {                          // CACHE_BOUNCE, iter == 1 (:466-472)

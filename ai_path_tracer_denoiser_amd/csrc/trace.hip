@@ -637,7 +637,7 @@ __device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur
 #define AIPT_POOL_COOP_LEAF 1
 #endif
 constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
-struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float4* rays; };   // this wave's LDS slices
+struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float2* rays; };   // this wave's LDS slices
 // inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)
 __device__ __forceinline__ int wave_incl_scan(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);     // row_shr:1
@@ -658,8 +658,9 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
     const unsigned long long mine = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
     if (at_leaf) {
         cl.best[lane] = mine;
-        cl.rays[2 * lane] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);          // the owners' rays: two 16-byte reads per tester
-        cl.rays[2 * lane + 1] = make_float4(r.d.y, r.d.z, 0.0f, 0.0f);
+        cl.rays[3 * lane] = make_float2(r.o.x, r.o.y);                        // the owners' rays: three 8-byte reads per tester
+        cl.rays[3 * lane + 1] = make_float2(r.o.z, r.d.x);
+        cl.rays[3 * lane + 2] = make_float2(r.d.y, r.d.z);
         for (int k = 0; k < cnt; k++) cl.pairs[excl + k] = ((unsigned)lane << 26) | (unsigned)(first + k);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -670,8 +671,8 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
         const bool work = pi < total;
         const unsigned pr = cl.pairs[work ? pi : 0];
         const int owner = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
-        const float4 ra = cl.rays[2 * owner], rb = cl.rays[2 * owner + 1];
-        const v3 o = V(ra.x, ra.y, ra.z), d = V(ra.w, rb.x, rb.y);
+        const float2 ra = cl.rays[3 * owner], rb = cl.rays[3 * owner + 1], rc = cl.rays[3 * owner + 2];
+        const v3 o = V(ra.x, ra.y, rb.x), d = V(rb.y, rc.x, rc.y);
         unsigned long long key = ~0ull;
         if (work) {
             const uint4* tr = tris + (unsigned)slot * 3u;
@@ -792,7 +793,7 @@ __device__ __forceinline__ void camera_ray(const TraceParams& p, const aipt_came
 // (the nearest face is the nearest face; the caller lets it replace a primitive hit only when strictly nearer, as the
 // reference's loop does), so results do not depend on how rays were assigned to lanes.
 #ifndef AIPT_POOL_BLOCKS
-#define AIPT_POOL_BLOCKS 4
+#define AIPT_POOL_BLOCKS 6
 #endif
 constexpr int POOL_BLOCKS = AIPT_POOL_BLOCKS;
 #ifndef AIPT_POOL_REFILL
@@ -807,7 +808,7 @@ __device__ __forceinline__ int pool_blocks(int n) {                 // 256-path 
     const int k = n / (256 * 512);                                  // keep >= 512 workgroups
     return k < 1 ? 1 : k > POOL_BLOCKS ? POOL_BLOCKS : k;
 }
-__device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int2* s_res,
+__device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int* s_res,
                                           WalkStack& st, int lane, const CoopLeaf& cl) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
     const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
@@ -819,7 +820,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
     st.sp = 0;
     while (true) {
         if (cur == WALK_DONE && lid >= 0) {                         // finished since the last look: hand the result over
-            s_res[lid] = make_int2(__float_as_int(r.t_min), r.best_slot);
+            s_res[lid] = r.best_slot;                               // (the distance comes back with the winner's full test)
             lid = -1;
         }
         const unsigned long long idle = __ballot(cur == WALK_DONE);
@@ -832,7 +833,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
                 const int k = base + __popcll(idle & ((1ull << lane) - 1ull));
                 if (k < pool_n) {
                     lid = s_pool[k];
-                    const int i = s_res[lid].x;                     // the path index, parked there by the listing phase
+                    const int i = s_res[lid];                       // the path index, parked there by the listing phase
                     const float4 a = S0[i], b = S1[i];
                     r.start(V(a.x, a.y, a.z), V(a.w, b.x, b.y), FLT_MAX);
                     cur = 0;
@@ -884,8 +885,8 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     int* s_stack = s_dyn;
     int* s_pool = s_dyn + STACK_LDS * 256;                                            // POOL: local ids of the paths to walk
-    int2* s_res = reinterpret_cast<int2*>(s_pool + POOL_BLOCKS * 256);                // POOL: per local id (t, leaf slot)
-    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0) + (POOL ? POOL_BLOCKS * 256 * 3 : 0));
+    int* s_res = s_pool + POOL_BLOCKS * 256;                                          // POOL: per local id: the walker's path index, then its leaf slot (-1: none)
+    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0) + (POOL ? POOL_BLOCKS * 256 * 2 : 0));
     aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     PHASE_INIT();
@@ -933,9 +934,9 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     __shared__ unsigned s_pairs[MESH && AIPT_POOL_COOP_LEAF ? 4 * COOP_PAIRS : 1];
     __shared__ unsigned long long s_best[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
     __shared__ int s_slot[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
-    __shared__ float4 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 512 : 1];
+    __shared__ float2 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 768 : 1];
     const CoopLeaf cl{s_pairs + (MESH && AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
-                      s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 128 : 0)};
+                      s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 192 : 0)};
     if (POOL) {
         // ---- list the paths of this workgroup's blocks that enter the mesh box, walk them all, leave (t, leaf slot) per path
         for (int j = 0; j < K; j++) {
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             int base = 0;
             if (lane == 0 && m) base = atomicAdd(&s_pool_n, __popcll(m));
             base = __shfl(base, 0);
-            s_res[j * 256 + tid] = make_int2(i, -1);                // the path index for the walker; "no face" for everyone else
+            s_res[j * 256 + tid] = walker ? i : -1;                 // the path index for the walker; "no face" for everyone else
             if (walker) s_pool[base + __popcll(m & ((1ull << lane) - 1ull))] = j * 256 + tid;
         }
         __syncthreads();
@@ -1067,13 +1068,13 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
         }
         PHASE(1);
         if (POOL && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
-            const int2 w = s_res[j * 256 + tid];                    // nearest face of the pooled walk (slot -1: none)
-            if (w.y >= 0 && t_min > __int_as_float(w.x)) {          // a face replaces a primitive hit only when strictly nearer (:262)
+            const int w = s_res[j * 256 + tid];                     // nearest face of the pooled walk (slot -1: none)
+            if (w >= 0) {
                 DevFace f;
-                load_leaf_face(p, w.y, f);
+                load_leaf_face(p, w, f);
                 v3 tp, tn;
-                const float t = triangleTest(f, o, d, tp, tn);
-                t_min = t; materialid = f.materialid; hitP = tp; normal = tn;
+                const float t = triangleTest(f, o, d, tp, tn);      // (the walk's distance of this face, same bits)
+                if (t_min > t) { t_min = t; materialid = f.materialid; hitP = tp; normal = tn; }   // a face replaces a primitive hit only when strictly nearer (:262)
             }
         } else if (walk_mesh && ((p.flags & AIPT_TRACE_NO_CULL) || rayAABB(o, d, p.box))) {   // RAY_CULLING true (:23, :258) / false (:270-281)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
@@ -1708,7 +1709,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     // (from 4 frames on: at 2 frames both walks take 0.82 ms per frame, single frames lose 10 %; never on bounce 0, whose camera
     // rays are coherent -- 0.48 SIMD efficiency in the fused walk -- and would be generated twice: 415 vs 476 us at 8 frames)
     const bool pool = mesh && (pool_env < 0 ? nframes >= 4 : pool_env != 0);
-    const size_t pool_bytes = stack_bytes + (size_t)POOL_BLOCKS * 256 * 3 * sizeof(int);
+    const size_t pool_bytes = stack_bytes + (size_t)POOL_BLOCKS * 256 * 2 * sizeof(int);
     snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s,false>", mesh ? "true" : "false");
     snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
     int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)

@@ -13,8 +13,8 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
     node has fewer GPUs); under torch.distributed.run: one rank per GPU, frames are sharded in contiguous chunks, rank 0
     packs the scene (BVH built once) and the weights and broadcasts them over RCCL; no per-frame collective -> "scaling": "weak".
 
-Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds 32
-consecutive frames.  Their traces share one set of bounce launches per up to 24 frames (a single 1280x720 frame leaves most of the
+Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds up to 24
+consecutive frames (--batch; at most 32).  Their traces share one set of bounce launches per up to 24 frames (a single 1280x720 frame leaves most of the
 chip idle in its later bounces; the frames are interleaved pixel by pixel and a workgroup pools the BVH walks of 1024 paths,
 refilling idle lanes).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
 it, so the many small launches of one frame's deep levels run beside the full-size layers of the other; the hidden state is
@@ -97,7 +97,7 @@ def parse_args(argv=None):
     args.mesh_kind = args.mesh_kind or kind or "atrium"
     args.impl = args.impl or impl
     if args.batch is None:
-        args.batch = 32
+        args.batch = 24                                     # = AIPT_TRACE_BATCH_MAX: a call's traces are ONE set of launches (32: 16 + 16; 851 vs 840 frames/s)
     return args
 
 
@@ -211,11 +211,11 @@ class Workload:
         self.cams = [self.camera_for(g) for g in self.frames]
 
     def trace_call_sizes(self, k0, k1):
-        """frames held by every trace call run_frames(k0, k1) makes (aipt_frames splits a batch evenly over ceil(n/16) calls)"""
+        """frames held by every trace call run_frames(k0, k1) makes (aipt_frames splits a batch evenly over ceil(n/24) calls)"""
         sizes, k = [], k0
         while k < k1:
             nb = min(self.B, k1 - k)
-            nc = (nb + 15) // 16
+            nc = (nb + 23) // 24
             sizes += [nb // nc + (1 if c < nb % nc else 0) for c in range(nc)]
             k += nb
         return sizes

@@ -112,12 +112,12 @@ def test_bench_default_32_frame_call_configs2_full_size():
 
 
 def test_driver_command_20_frames_after_5_warmup_configs2():
-    """`bench.py --steps 20 --warmup 5` (the driver's command): a 5-frame call, then a 20-frame call traced 10 + 10 with the
-    hidden state carried across the calls; every denoised frame equals the frame-by-frame sequence and the G-buffers of the
-    second call's launch sets equal the oracle."""
+    """`bench.py --steps 20 --warmup 5` (the driver's command): a 5-frame call, then a 20-frame call traced by ONE set of launches
+    (round 4: up to 24 frames per set; rounds 2-3 traced it 10 + 10) with the hidden state carried across the calls; every
+    denoised frame equals the frame-by-frame sequence and G-buffers across the 20-frame launch set equal the oracle."""
     N = 25
-    wl = _workload(2, 32, N)
-    assert wl.trace_call_sizes(5, 25) == [10, 10]
+    wl = _workload(2, 24, N)                                                   # bench.py's default --batch
+    assert wl.trace_call_sizes(5, 25) == [20] and wl.trace_call_sizes(0, 5) == [5]
     got = []
 
     def keep(k, nb):

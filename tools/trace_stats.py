@@ -17,7 +17,7 @@ def main():
     from ai_path_tracer_denoiser_amd import api, synth
     ntri = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1           # frames traced together (interleaved batch)
-    W, H, depth = 1280, 720, 8
+    W, H, depth = 1280, 720, int(os.environ.get("STATS_DEPTH", 8))     # STATS_DEPTH=1: the phase shares of bounce 0 alone
     sc = api.Scene(os.path.join(ROOT, "scenes", "cornell.txt"), res=(W, H), depth=depth)
     stone = api.Material.from_buffer_copy(synth.STONE)
     mats = list(sc.materials) + [stone]

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include <algorithm>
+#include <cmath>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 // sense-free counting barrier: every workgroup adds 1, then spins until the counter reaches nwg * (phase + 1)
@@ -32,19 +33,19 @@ __global__ __launch_bounds__(256) void phases(float* buf, unsigned* ctr, int nph
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (int p = 0; p < nphases; p++) {
         // a little dependent work: every element becomes a function of an element another workgroup wrote in the last phase
-        for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = buf[((p + 1) & 1) * n + (i + 4099) % n] * 0.999f + 1.0f;
+        for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = fmaf(buf[((p + 1) & 1) * n + (i + 4099) % n], 0.999f, 1.0f);
         grid_barrier<MODE>(ctr, gridDim.x * (unsigned)(p + 1));
     }
 }
 __global__ __launch_bounds__(256) void one_phase(float* buf, int p, int n) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = buf[((p + 1) & 1) * n + (i + 4099) % n] * 0.999f + 1.0f;
+    for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = fmaf(buf[((p + 1) & 1) * n + (i + 4099) % n], 0.999f, 1.0f);
 }
 
 // ---- round 4: the same phases among the workgroups of ONE XCD only.  Their stores meet in that XCD's L2, so
 // the barrier needs no L2 write-back (the agent-scope release that costs the cross-XCD form its 5-15 us): release = wait for this
-// workgroup's stores to reach L2 (workgroup-scope fence), arrive and spin by L2 atomics (no scope bits: executed in the XCD's L2,
-// never served from an L1), acquire = invalidate this CU's L1 (agent-scope acquire fence).  The launch covers the chip (8 N
+// workgroup's stores to reach L2 (workgroup-scope fence), arrive by an L2 atomic (no scope bits: executed in the XCD's L2), spin on
+// loads that bypass the L1, acquire = invalidate this CU's L1 (agent-scope acquire fence).  The launch covers the chip (8 N
 // workgroups); a workgroup reads HW_REG_XCC_ID and leaves unless it runs on XCD 0.  The result is checked against a host
 // replay of the phases: a stale read would show.
 __device__ __forceinline__ unsigned xcc_id() {
@@ -57,7 +58,12 @@ __device__ __forceinline__ void xcd_barrier(unsigned* ctr, unsigned target) {
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_fetch_add(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+        // (bounded: if fewer workgroups than expected run on this XCD the barrier would never open -- give up and flag it)
+        unsigned spins = 0;
+        // (an agent-scope relaxed load: never served from this CU's L1, no fence; a workgroup-scope fetch_add(0) is folded into a
+        // plain load by the compiler, stays in L1 and never sees the others arrive)
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < 4000000u) __builtin_amdgcn_s_sleep(1);
+        if (spins >= 4000000u) __hip_atomic_fetch_or(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -72,15 +78,16 @@ __global__ __launch_bounds__(256) void phases_one_xcd(float* buf, unsigned* ctr,
     if (rank >= (unsigned)nwg_xcd) return;                      // (more workgroups of the launch landed here than expected: they sit out)
     const int gid = rank * blockDim.x + threadIdx.x, gsz = nwg_xcd * blockDim.x;
     for (int p = 0; p < nphases; p++) {
-        for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = buf[((p + 1) & 1) * n + (i + 4099) % n] * 0.999f + 1.0f;
+        for (int i = gid; i < n; i += gsz) buf[(p & 1) * n + i] = fmaf(buf[((p + 1) & 1) * n + (i + 4099) % n], 0.999f, 1.0f);
         xcd_barrier(ctr, (unsigned)nwg_xcd * (unsigned)(p + 1));
+        if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;      // a barrier timed out somewhere: stop
     }
 }
 
 int main() {
     const int n = 1 << 18, P = 64;
     float* buf; unsigned* ctr;
-    CK(hipMalloc((void**)&buf, 2 * n * 4)); CK(hipMalloc((void**)&ctr, 4));
+    CK(hipMalloc((void**)&buf, 2 * n * 4)); CK(hipMalloc((void**)&ctr, 8));
     CK(hipMemset(buf, 0, 2 * n * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int nwg : {48, 144, 256, 512}) {
@@ -108,16 +115,18 @@ int main() {
         }
         printf("%3d workgroups x 256 threads, %d dependent phases over %d floats: one cooperative launch %.2f us per phase (acquire spins) / %.2f (relaxed spins + fences); %d launches %.2f us per phase\n",
                nwg, P, n, bestm[0] * 1e3f / P, bestm[1] * 1e3f / P, P, best2 * 1e3f / P);
+        fflush(stdout);
     }
     // ---- one XCD
     unsigned* rank_ctr; CK(hipMalloc((void**)&rank_ctr, 4));
     std::vector<float> ref(2 * n), got(2 * n);
+    const int n1 = 1 << 14;                                       // 64 KB per phase: the phase IS the barrier
     for (int nx : {6, 18, 32}) {                                 // workgroups on XCD 0 (of 8 nx launched): 48 / 144 / 256 chip-wide equivalents
         float best = 1e9f; bool ok = true; unsigned landed = 0;
         for (int rep = 0; rep < 5; rep++) {
-            CK(hipMemset(ctr, 0, 4)); CK(hipMemset(rank_ctr, 0, 4)); CK(hipMemset(buf, 0, 2 * n * 4));
+            CK(hipMemset(ctr, 0, 8)); CK(hipMemset(rank_ctr, 0, 4)); CK(hipMemset(buf, 0, 2 * n * 4));
             CK(hipDeviceSynchronize());
-            int np = P, nn = n, nwx = nx;
+            int np = P, nn = n1, nwx = nx;
             void* args[] = {&buf, &ctr, &rank_ctr, &np, &nn, &nwx};
             CK(hipEventRecord(e0, 0));
             CK(hipLaunchCooperativeKernel(reinterpret_cast<void*>(phases_one_xcd), dim3(8 * nx), dim3(256), args, 0, 0));
@@ -125,14 +134,17 @@ int main() {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1));
             best = ms < best ? ms : best;
             CK(hipMemcpy(&landed, rank_ctr, 4, hipMemcpyDeviceToHost));
+            unsigned flags[2]; CK(hipMemcpy(flags, ctr, 8, hipMemcpyDeviceToHost));
+            if (flags[1]) { printf("ONE XCD: %d workgroups expected on XCD 0, %u landed: a barrier timed out\n", nx, landed); fflush(stdout); ok = false; break; }
             CK(hipMemcpy(got.data(), buf, 2 * n * 4, hipMemcpyDeviceToHost));
             std::fill(ref.begin(), ref.end(), 0.0f);
             for (int p = 0; p < P; p++)
-                for (int i = 0; i < n; i++) ref[(p & 1) * n + i] = ref[((p + 1) & 1) * n + (i + 4099) % n] * 0.999f + 1.0f;
-            for (int i = 0; i < 2 * n; i++) ok = ok && got[i] == ref[i];
+                for (int i = 0; i < n1; i++) ref[(p & 1) * n1 + i] = fmaf(ref[((p + 1) & 1) * n1 + (i + 4099) % n1], 0.999f, 1.0f);
+            for (int i = 0; i < 2 * n1; i++) ok = ok && got[i] == ref[i];
         }
-        printf("ONE XCD: %2d workgroups x 256 threads on XCD 0 (%u of the %d launched landed there), %d dependent phases: %.2f us per phase; result %s\n",
-               nx, landed, 8 * nx, P, best * 1e3f / P, ok ? "equals the host replay" : "DIFFERS from the host replay (stale reads)");
+        printf("ONE XCD: %2d workgroups x 256 threads on XCD 0 (%u of the %d launched landed there), %d dependent phases over 16384 floats: %.2f us per phase; result %s\n",
+               nx, landed, 8 * nx, P, best * 1e3f / P, ok ? "equals the host replay" : "DIFFERS from the host replay (stale reads) or timed out");
+        fflush(stdout);
     }
     return 0;
 }

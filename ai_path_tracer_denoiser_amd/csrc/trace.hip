@@ -922,9 +922,12 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     }
     if (POOL && tid == 0) { s_pool_n = 0; s_head = 0; }
     if (FIRST) {
-        const int wv = __builtin_amdgcn_readfirstlane(wave);               // provably wave-uniform: p.cams[f] below is s_load
-        for (int f = wv; f < p.nframes; f += 4)
-            if (lane == 0) s_cams[f] = p.cams[f];
+        // all 256 threads copy the cameras (21 dwords each) from the kernel-argument segment: one or two loads per thread (one lane
+        // per wave copying whole structs was a chain of ~100 dependent scalar loads and LDS stores in front of every workgroup)
+        static_assert(sizeof(aipt_camera) % 4 == 0, "camera copy by dwords");
+        const int nw = p.nframes * (int)(sizeof(aipt_camera) / 4);
+        const int* src = reinterpret_cast<const int*>(p.cams);
+        for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_cams)[k] = src[k];
     }
     __syncthreads();
     PHASE(0);

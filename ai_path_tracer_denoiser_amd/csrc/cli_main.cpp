@@ -9,7 +9,7 @@
 //   aiptd scene.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE | --synthetic-weights SEED]
 //                   [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w] [--pan AMPLITUDE] [--device I]
 //                   [--no-aa] [--no-compaction] [--sort-material] [--cache-first-bounce] [--motion-blur] [--no-cull]
-//                   [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth] [--dump-weights FILE]
+//                   [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth] [--hdr] [--dump-weights FILE]
 //                   [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]
 //
 // The reference's compile-time switches are run-time flags: STREAM_COMPACTION / SORT_MATERIAL / CACHE_BOUNCE /
@@ -177,6 +177,31 @@ bool write_npy(const std::string& path, const float* data, int c, int h, int w) 
     fclose(f);
     return ok;
 }
+// Radiance .hdr (RGBE) of a planar float RGB image: image::saveHDR (Inference/src/image.cpp:59-63 -> stbi_write_hdr).  The pixel
+// encoding is the published RGBE one stb uses (shared exponent of the largest component, frexp(max) * 256 / max, truncation);
+// scanlines are written flat (un-run-length-encoded), which every Radiance reader accepts.
+bool write_hdr(const std::string& path, const float* base, size_t plane, int stride, int w, int h) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "#?RADIANCE\n# Written by aiptd\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y %d +X %d\n", h, w);
+    std::vector<unsigned char> row((size_t)w * 4);
+    bool ok = true;
+    for (int y = 0; y < h && ok; y++) {
+        for (int x = 0; x < w; x++) {
+            const float r = base[(size_t)y * stride + x], g = base[plane + (size_t)y * stride + x], b = base[2 * plane + (size_t)y * stride + x];
+            const float m = std::fmax(r, std::fmax(g, b));
+            unsigned char* o = &row[(size_t)x * 4];
+            if (!(m >= 1e-32f)) { o[0] = o[1] = o[2] = o[3] = 0; continue; }
+            int e;
+            const float norm = std::frexp(m, &e) * 256.0f / m;
+            o[0] = (unsigned char)(r > 0 ? r * norm : 0); o[1] = (unsigned char)(g > 0 ? g * norm : 0); o[2] = (unsigned char)(b > 0 ? b * norm : 0);
+            o[3] = (unsigned char)(e + 128);
+        }
+        ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+    }
+    fclose(f);
+    return ok;
+}
 unsigned char q8(float v, float scale) {
     const float x = v * scale;
     return (unsigned char)(x <= 0.0f ? 0 : (x >= 255.0f ? 255 : (int)x));
@@ -201,6 +226,7 @@ struct Options {
     int gpus = 1, ranks = 0, batch = 1, reset_every = 0;
     int spp = 1;                      // iterations accumulated per frame (--spp N; --ground-truth: the scene's ITERATIONS)
     bool ground_truth = false, recompute_normals = false;
+    bool hdr = false;                 // also write Radiance .hdr files of the float images (image::saveHDR)
     bool prefetch = false;
     bool npy = false, shim = false;
     uint64_t wseed = 565;
@@ -311,6 +337,12 @@ void render(const Shared& sh, Rank& rk) {
                 const auto gt = to_image(h_g.data(), plane, stride, W, H, 3, 255.0f);       // planes 0-2 = image / spp
                 ok = ok && write_png(o.out_dir + "/GroundTruth" + name + ".png", gt.data(), W, H, 3);
             }
+            if (o.hdr) {
+                // the unclamped float images beside the 8-bit ones (which are image::savePNG_scaled: clamp to [0, 1], x 255, truncate)
+                ok = ok && write_hdr(o.out_dir + "/Denoised" + name + ".hdr", h_o.data(), (size_t)W * H, W, W, H) &&
+                     write_hdr(o.out_dir + "/RGB" + name + ".hdr", o.spp > 1 ? h_g1.data() : h_g.data(), plane, stride, W, H);
+                if (o.spp > 1) ok = ok && write_hdr(o.out_dir + "/GroundTruth" + name + ".hdr", h_g.data(), plane, stride, W, H);
+            }
             if (o.npy) {
                 // the G-buffer with its padding stripped: [10][H][W]
                 std::vector<float> g((size_t)10 * W * H);
@@ -347,7 +379,7 @@ int main(int argc, char** argv) {
         printf("Usage: %s SCENEFILE.txt [--frames N] [--out DIR] [--npy] [--res W H] [--depth D] [--weights FILE |"
                " --synthetic-weights SEED] [--bn batch|running] [--hidden carry|reset] [--impl f32|f16x3|f16w]"
                " [--pan AMPLITUDE] [--device I] [--no-aa] [--no-compaction] [--sort-material] [--cache-first-bounce]"
-               " [--motion-blur] [--no-cull] [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth]"
+               " [--motion-blur] [--no-cull] [--dielectric] [--mesh-normal-view] [--recompute-normals] [--spp N | --ground-truth] [--hdr]"
                " [--dump-weights FILE] [--gpus N] [--ranks R] [--shim] [--batch B] [--prefetch] [--reset-every C]\n", argv[0]);
         return 1;
     }
@@ -384,6 +416,7 @@ int main(int argc, char** argv) {
         else if (a == "--mesh-normal-view") o.tr_flags |= AIPT_TRACE_MESH_NORMAL_VIEW;           // MESH_NORMAL_VIEW (interactions.h:4)
         else if (a == "--recompute-normals") o.recompute_normals = true;                         // RECOMPUTE_NORMALS (scene.cpp:9)
         else if (a == "--spp") { need(1); o.spp = atoi(argv[++i]); }
+        else if (a == "--hdr") o.hdr = true;                                                     // image::saveHDR (image.cpp:59)
         else if (a == "--ground-truth") o.ground_truth = true;                                   // GROUND_TRUTH (main.cpp:41)
         else if (a == "--gpus") { need(1); o.gpus = atoi(argv[++i]); }
         else if (a == "--ranks") { need(1); o.ranks = atoi(argv[++i]); }

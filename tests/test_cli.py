@@ -211,3 +211,27 @@ def test_cli_motion_blur_moves_the_primitives_every_fourth_iteration(tmp_path):
         sc.pathtrace(iter=it, accum=accum, gbuf=g_ref)
     assert np.array_equal(outs["blur"], g_ref)
     assert not np.array_equal(outs["still"], g_ref)
+
+
+@pytest.mark.gpu
+def test_cli_hdr_output(tmp_path):
+    """--hdr = image::saveHDR (Inference/src/image.cpp:59-63): Radiance RGBE files of the float images beside the 8-bit PNGs (which are
+    image::savePNG_scaled, :41-57: clamp to [0, 1], x 255, truncate).  Decoded RGBE equals the float tensor to the format's
+    resolution (8 bits under the largest component's exponent)."""
+    W, H, depth = 96, 64, 3
+    out = tmp_path / "o"
+    r = subprocess.run([CLI, CORNELL, "--frames", "1", "--res", str(W), str(H), "--depth", str(depth), "--out", str(out), "--npy", "--hdr",
+                        "--impl", "f32"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name, ref in (("Denoised", np.load(out / "frame_0000_denoised.npy")), ("RGB", np.load(out / "frame_0000_gbuffer.npy")[0:3])):
+        raw = (out / name / "frame_0000.hdr").read_bytes()
+        head, _, body = raw.partition(b"\n\n")
+        assert head.startswith(b"#?RADIANCE") and b"FORMAT=32-bit_rle_rgbe" in head
+        dims, _, pix = body.partition(b"\n")
+        assert dims == f"-Y {H} +X {W}".encode() and len(pix) == W * H * 4
+        q = np.frombuffer(pix, np.uint8).reshape(H, W, 4).astype(np.float64)
+        scale = np.where(q[..., 3] > 0, np.ldexp(1.0, (q[..., 3] - 136).astype(np.int64)), 0.0)       # 2^(e - 128) / 256
+        got = (q[..., :3] * scale[..., None]).transpose(2, 0, 1)
+        want = np.maximum(ref.astype(np.float64), 0.0)
+        step = np.maximum(want.max(axis=0), 1e-32)[None] / 128.0                                     # one unit of the shared mantissa, at most
+        assert (np.abs(got - want) <= step + 1e-30).all(), name

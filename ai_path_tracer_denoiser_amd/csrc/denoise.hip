@@ -6,20 +6,21 @@
 //
 // Data layout in HBM: every activation is fp32 in the channel-quad interleaved "C4" layout [C/4][h][w][4] (see ConvSrc);
 // the planar G-buffer input is read as it is by the first conv.
-// Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and
-// adds its per-channel sum / sum of squares to the layer's statistics table (64-bit fixed-point atomics, 8 replicas); the CONSUMER turns
-// them into the per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a) in its prologue (BnRef / bn_ab) and
-// applies x -> lrelu(a*x+b) while it stages its input tile into LDS, so BatchNorm, LeakyReLU, channel concat (two source
-// pointers) and nearest upsample (source indexed at (y>>1, x>>1)) never touch HBM as separate passes and there is no
-// launch between two convs.  Zero padding is applied in the normalised domain (out-of-image taps load 0, not f(0)).
-// MaxPool needs normalised values, so one small pool kernel per encoder level materialises the pooled, normalised skip
-// tensor (quarter size).
+// Each conv writes its RAW output (conv + bias, optionally LeakyReLU for the encoder's conv->LReLU->BN order) once and adds its
+// per-channel sum / sum of squares to the layer's statistics table (two-word fixed-point atomics, 8 replicas); the CONSUMER turns
+// them into the per-channel affine (a, b) = (gamma/sqrt(var+eps), beta - mean*a) in its prologue (BnRef / bn_ab) and applies
+// x -> lrelu(a*x+b) while it stages its input, so BatchNorm, LeakyReLU, channel concat (two source pointers) and nearest upsample
+// (source indexed at (y>>1, x>>1)) never touch HBM as separate passes and there is no launch between two convs.  Zero padding is
+// applied in the normalised domain (out-of-image taps load 0, not f(0)).  MaxPool is the 2x2 max (min where gamma < 0) of the raw
+// output in the producing conv's epilogue; the network's last BatchNorm + crop is the second pass of the output layer.
 //
-// Kernels: conv3x3_f16x3r -- the two big levels (>= 368 x 640, the planar-input first conv included): persistent, register-staged
-// implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into fp16 hi/lo pairs, weights resident in LDS, no barriers;
-// conv3x3_f16x3 -- the same arithmetic LDS-tiled and barrier-phased (the levels below, and the depth-to-space form of dec1.c1);
-// conv3x3_mfma -- the same GEMM on v_mfma_f32_16x16x4_f32 (exact fp32 products and accumulation; the deep levels, and
-// everything under AIPT_DN_IMPL_MFMA); conv3x3_quad -- the 3 -> 3 output layer.  Rooflines and measurements: DESIGN.md.
+// Kernels: conv3x3_f16x3r -- the two big levels (>= 368 x 640, the planar-input first conv and the depth-to-space form of dec1.c1
+// included): persistent, register-staged implicit GEMM on v_mfma_f32_32x32x16_f16 with fp32 operands split into fp16 hi/lo pairs,
+// weights resident in LDS, no barriers; conv3x3_f16x3 -- the same arithmetic LDS-tiled and barrier-phased (the levels below; 4-row
+// tiles with three waves per row where all of them fit the chip at once); conv3x3_mfma -- the same GEMM on v_mfma_f32_16x16x4_f32
+// (exact fp32 products and accumulation: AIPT_DN_IMPL_MFMA, and levels beyond the fp16 operand range); conv3x3_quad -- the 3 -> 3
+// output layer as two streaming passes.  Which kernel runs a level: run_conv + aipt_denoise_set_option (include/aiptd.h); no
+// environment variable takes part.  Rooflines and measurements: DESIGN.md.
 #include "internal.h"
 
 #include <cmath>
@@ -1739,9 +1740,6 @@ static int conv_nblk(const TileChoice& t, int H, int W) {
     return ((W + 16 * t.mbx - 1) / (16 * t.mbx)) * ((H + 4 * t.rw - 1) / (4 * t.rw));
 }
 
-// conv + (stats ->) finalize.  `dst` receives the raw output and its (a,b).
-// true when the conv of an h x w level runs on the split-fp16 kernel in a one-row-per-wave instantiation: those fuse the 2x2
-// pool of an encoder block's output into their epilogue (ConvArgsH::pool_out)
 // May a conv of an H x W level hold its NORMALISED input activations y = lrelu(a x + b) as fp16 pairs with |y| * scale <= 65 504?
 // With batch statistics |y| <= |gamma| sqrt(n - 1) + |beta| over the n pixels the statistics ran over (one outlier carrying all
 // of the variance), so the answer follows from the loaded weights: limit = 4 000 for conv3x3_f16x3r (activations times 2^4: beyond
@@ -1760,6 +1758,8 @@ static bool conv_fuses_pool(const DenoiseState* s, bool batch, int H, int W) {
     return s->opt_fused_pool && impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0);
 }
 
+// One conv layer: picks the kernel for the level (implementation, size, operand range), launches it and leaves in `dst` the raw
+// output together with how its consumers normalise it (batch statistics accumulated by the launch, or the running-statistics affine).
 static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int upA, const Tensor* B, int upB,
                     int H, int W, int out_lrelu, Tensor& dst, bool batch, bool use_b, const Tensor* pool_dst = nullptr,
                     float* final_out = nullptr, int final_h = 0, int final_w = 0) {

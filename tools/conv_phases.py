@@ -36,7 +36,10 @@ def main():
     pad16 = lambda c: (c + 15) // 16 * 16
     # (name, level, nchunks, cout): nchunks = chunks of a + chunks of b
     layers = [("enc1.l2a 64->32", 0, 4, 32), ("enc1.l2b 32->32", 0, 2, 32), ("enc2.l2a 86->43", 1, 6, 43),
-              ("enc2.l2b 43->43", 1, 3, 43), ("dec2.c1 86->32", 1, 6, 32), ("enc3.l2a 114->57", 2, 8, 57)]
+              ("enc2.l2b 43->43", 1, 3, 43), ("dec2.c1 86->32", 1, 6, 32), ("enc3.l2a 114->57", 2, 8, 57),
+              ("enc4.l2b 76->76", 3, 5, 76), ("enc5.l2b 101->101", 4, 7, 101), ("bott.l1 101->101", 5, 7, 101), ("dec5.c2 76->76", 4, 5, 76)]
+    if len(sys.argv) > 1 and sys.argv[1] == "small":               # the LDS-tiled kernel's own levels only (the big ones run conv3x3_f16x3r)
+        layers = layers[5:]
     out = (ctypes.c_ulonglong * 16)()
     for name, lvl, nch, cout in layers:
         key = ((W >> lvl) << 16) | (nch << 8) | cout

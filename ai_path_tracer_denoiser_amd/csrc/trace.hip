@@ -1522,6 +1522,8 @@ int aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes) {
     const int ngeoms = (int)v.h->ngeoms, nmats = (int)v.h->nmats, nfaces = (int)v.h->nfaces, nnodes = (int)v.h->nnodes;
     if (nmats <= 0 || (nfaces && (!nnodes || v.h->stack_need < 0 || v.h->stack_need > BVH_MAX_STACK)))
         return fail(ctx, AIPT_E_FORMAT, "aipt_scene_upload_packed: inconsistent header");
+    if (nfaces >= (1 << 26))       // the cooperative leaf step packs (lane, leaf slot) into 32 bits; leaf references hold slot * 8 + count
+        return fail(ctx, AIPT_E_INVALID, "aipt_scene_upload_packed: %d faces (at most %d)", nfaces, (1 << 26) - 1);
     for (int i = 0; i < ngeoms; i++)
         if (v.geoms[i].materialid < 0 || v.geoms[i].materialid >= nmats) return fail(ctx, AIPT_E_FORMAT, "packed scene: geom %d material", i);
     for (int k = 0; k < nfaces; k++)

@@ -636,6 +636,9 @@ __device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur
 #ifndef AIPT_POOL_COOP_LEAF
 #define AIPT_POOL_COOP_LEAF 1
 #endif
+#ifndef AIPT_POOL_TAIL_BOTH
+#define AIPT_POOL_TAIL_BOTH 1
+#endif
 constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
 struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float2* rays; };   // this wave's LDS slices
 // inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)
@@ -851,6 +854,19 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
             if (exhausted) break;
             continue;                                               // (unreachable: an all-idle wave always refills)
         }
+#if AIPT_POOL_TAIL_BOTH
+        // Once the pool has run dry the wave's last rays are a latency chain (42 % of a later bounce's node steps run after that,
+        // 30 % with at most 8 lanes at a node): nobody waits for company any more -- every lane at a leaf gets its (cheap,
+        // cooperative) leaf step and every lane at a node its node step in the same trip.
+        if (exhausted) {
+            if (nl) coop_leaf_step(tris, r, st, cur, cl, lane);
+            if (cur >= 0) {
+                STAT_ADD(0, 1); STAT_WAVE(1);
+                walk_node(nodes, r, st, cur);
+            }
+            continue;
+        }
+#endif
         if (nl >= POOL_LEAF || !any_node) {
             if (AIPT_POOL_COOP_LEAF) coop_leaf_step(tris, r, st, cur, cl, lane);
             else if (cur < 0 && cur != WALK_DONE) {

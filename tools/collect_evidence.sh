@@ -10,7 +10,7 @@ rm -rf $O; mkdir -p $O
 B="python bench.py"
 # PMC: the bench command with one denoiser stream, so that a counter belongs to one kernel (two kernels in flight share the
 # chip-wide counters); a bounce launch covers 16 frames either way
-P="$B --steps 16 --warmup 16 --no-cpu-baseline --no-roofline-events"   # (every batched trace launch holds 16 frames)
+P="$B --steps 20 --warmup 20 --no-cpu-baseline --no-roofline-events"   # (every batched trace launch holds 20 frames, as in the driver's command)
 pass() { tag=$1; shift; AIPT_DN_PIPELINE=0 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- $P > $O/pmc_$tag.log 2>&1; echo "pass $tag rc=$?"; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
@@ -19,7 +19,7 @@ pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INS
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
-python tools/pmc_summarize.py --frames-per-launch 16 --out $O/pmc_dominant.json $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv \
+python tools/pmc_summarize.py --frames-per-launch 20 --out $O/pmc_dominant.json $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv \
     'trace_bounce<false,true,true>' 'trace_bounce<true,true,false>' 'trace_bounce<false,true,false>' 'conv3x3_f16x3r<false,12,3,false,4,false>' 'conv3x3_f16x3r<false,8,3,false,4,true>' \
     'conv3x3_f16x3<1,8,false,false,1>' 'conv3x3_f16x3<1,4,false,false,3>' 'conv3x3_quad<3,3,false>' 'conv3x3_quad<3,3,true>'
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel trace_bounce --json $O/pmc_trace.json > /dev/null

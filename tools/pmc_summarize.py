@@ -54,7 +54,7 @@ def main():
     kernels = args[2:]
     f, w = per_launch(fcsv, "FETCH_SIZE"), per_launch(wcsv, "WRITE_SIZE")
     out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the default bench.py command "
-                     "with one denoiser stream (AIPT_DN_PIPELINE=0 ... --steps 16 --warmup 16 --no-cpu-baseline --no-roofline-events: "
+                     f"with one denoiser stream (AIPT_DN_PIPELINE=0 ... --steps {fpl or 20} --warmup {fpl or 20} --no-cpu-baseline --no-roofline-events: "
                      "a chip-wide counter belongs to one kernel only while one kernel runs); KiB -> bytes; FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md (gfx950 reports half of wide coalesced reads; the BVH walk's 16-byte gathers are not "
                      "the calibrated pattern, so its figure is an upper bound); WRITE_SIZE uncalibrated; averaged over all "

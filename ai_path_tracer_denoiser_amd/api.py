@@ -379,7 +379,7 @@ class Context:
         self._ck(lib().aipt_denoise_set_impl(self._h, impl))
 
     def denoise_set_option(self, option, value):
-        """aipt_denoise_set_option: DN_OPT_R_MINPIX / DN_OPT_F16_MINPIX / DN_OPT_SMALL_MINPIX / DN_OPT_FUSED_POOL"""
+        """aipt_denoise_set_option: DN_OPT_R_MINPIX / DN_OPT_F16_MINPIX / DN_OPT_SMALL_MINPIX / DN_OPT_FUSED_POOL / DN_OPT_KY_SPLIT"""
         self._ck(lib().aipt_denoise_set_option(self._h, option, value))
 
     def denoise(self, x10, out3, bn_batch: bool = True, carry: bool = False):

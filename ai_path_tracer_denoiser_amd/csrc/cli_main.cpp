@@ -31,6 +31,7 @@
 // --batch B (<= 32) traces B consecutive frames with one set of launches per up to 24 and pipelines their denoiser passes over two
 // streams (aipt_frames; identical results).  --prefetch (frame by frame, every rank on its own GPU): the next frame's trace
 // runs beside this frame's denoise on disjoint halves of the CUs (aipt_frame_prefetch; identical results).
+#include <cfloat>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -188,13 +189,17 @@ bool write_hdr(const std::string& path, const float* base, size_t plane, int str
     bool ok = true;
     for (int y = 0; y < h && ok; y++) {
         for (int x = 0; x < w; x++) {
-            const float r = base[(size_t)y * stride + x], g = base[plane + (size_t)y * stride + x], b = base[2 * plane + (size_t)y * stride + x];
+            // non-finite components (a degraded, unclamped frame) are written as the largest float: frexp of inf has no exponent
+            // and a NaN or out-of-range mantissa cast to unsigned char is undefined
+            auto fin = [](float v) { return v != v ? 0.0f : std::fmin(v, FLT_MAX); };
+            const float r = fin(base[(size_t)y * stride + x]), g = fin(base[plane + (size_t)y * stride + x]), b = fin(base[2 * plane + (size_t)y * stride + x]);
             const float m = std::fmax(r, std::fmax(g, b));
             unsigned char* o = &row[(size_t)x * 4];
             if (!(m >= 1e-32f)) { o[0] = o[1] = o[2] = o[3] = 0; continue; }
             int e;
             const float norm = std::frexp(m, &e) * 256.0f / m;
-            o[0] = (unsigned char)(r > 0 ? r * norm : 0); o[1] = (unsigned char)(g > 0 ? g * norm : 0); o[2] = (unsigned char)(b > 0 ? b * norm : 0);
+            auto mant = [norm](float v) { const float q = v > 0 ? v * norm : 0.0f; return (unsigned char)(q >= 255.0f ? 255 : (int)q); };
+            o[0] = mant(r); o[1] = mant(g); o[2] = mant(b);
             o[3] = (unsigned char)(e + 128);
         }
         ok = fwrite(row.data(), 1, row.size(), f) == row.size();

@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
     const int nch = g.nchunks, ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up;
     float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
-    float* bias_s = tab_b + nch * KH;                          // [32], times 2^11: the accumulators start from it
+    float* bias_s = tab_b + nch * KH;                          // [32], times the operand scaling (2^4 2^7 = 2^11, or 2^-4 with PLANAR): the accumulators start from it
     long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][BN_WORDS]
     const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [8]: the BN coefficients of out-of-image pixels
 
@@ -1177,6 +1177,11 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                     const int e = (p & 1) * 2;
                     float v0 = fmaf(aa[e], rw[e], bb[e]), v1 = fmaf(aa[e + 1], rw[e + 1], bb[e + 1]);
                     if (!PLANAR) { v0 = fmaxf(v0, v0 * slope); v1 = fmaxf(v1, v1 * slope); }   // (the network input has no LeakyReLU: the host checks)
+                    else {
+                        // the caller's units: |x| 2^-4 beyond fp16's 65 504 saturates HERE, so that the low half stays finite
+                        // ((v - hi) 2^11 of an unclamped v is inf, and inf x 0 of a pad weight is NaN for the whole frame)
+                        v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f); v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
+                    }
                     xh[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
                     xl[p] = PLANAR ? split_lo_mix_scaled(xh[p], v0 * LO_SCALE, v1 * LO_SCALE, -LO_SCALE) : split_lo_mix(xh[p], v0, v1);
                     if (WC) { xh[p] = ok ? xh[p] : 0u; xl[p] = ok ? xl[p] : 0u; }
@@ -1740,22 +1745,32 @@ static int conv_nblk(const TileChoice& t, int H, int W) {
     return ((W + 16 * t.mbx - 1) / (16 * t.mbx)) * ((H + 4 * t.rw - 1) / (4 * t.rw));
 }
 
-// May a conv of an H x W level hold its NORMALISED input activations y = lrelu(a x + b) as fp16 pairs with |y| * scale <= 65 504?
-// With batch statistics |y| <= |gamma| sqrt(n - 1) + |beta| over the n pixels the statistics ran over (one outlier carrying all
-// of the variance), so the answer follows from the loaded weights: limit = 4 000 for conv3x3_f16x3r (activations times 2^4: beyond
-// 4 094 the hi half saturates, beyond 8 190 the lo half becomes inf and inf x 0 = NaN spreads over the frame), 65 000 for
-// conv3x3_f16x3.  A level that fails a limit runs on the next kernel down (conv3x3_f16x3, then the exact f32 MFMA kernel, which
-// has the range of fp32).  Running statistics bound nothing: there the caller keeps |y| < 4 094 (include/aiptd.h) or selects
-// AIPT_DN_IMPL_MFMA.
-static bool f16_range_ok(const DenoiseState* s, bool batch, int H, int W, double limit) {
+// May a conv hold its NORMALISED input activations y = lrelu(a x + b) as fp16 pairs with |y| * scale <= 65 504?
+// With batch statistics |y| <= |gamma| sqrt(n - 1) + |beta| over the n pixels THE STATISTICS RAN OVER (one outlier carrying all
+// of the variance) -- the producer's pixel count, not the consumer's: the first conv of encoder level i >= 1 and the
+// depth-to-space dec1.c1 read a fused-pool tensor whose statistics ran over four times their own pixels (rounds 3-4 used the
+// consumer's H x W there and under-estimated the bound by 2x: ADVICE r4).  So the answer follows from the loaded weights and the
+// sources' BnRef: limit = 4 000 for conv3x3_f16x3r (activations times 2^4: beyond 4 094 the hi half saturates, beyond 8 190 the
+// lo half becomes inf and inf x 0 = NaN spreads over the frame), 65 000 for conv3x3_f16x3.  A level that fails a limit runs on
+// the next kernel down (conv3x3_f16x3, then the exact f32 MFMA kernel, which has the range of fp32).  Running statistics bound
+// nothing: there the caller keeps |y| < 4 094 (include/aiptd.h) or selects AIPT_DN_IMPL_MFMA.
+static bool f16_range_ok(const DenoiseState* s, bool batch, double stat_pixels, double limit) {
     if (!batch) return true;
-    const double bound = (double)s->bn_gmax * sqrt((double)H * (double)W) + (double)s->bn_bmax;
+    const double bound = (double)s->bn_gmax * sqrt(stat_pixels) + (double)s->bn_bmax;
     return bound < limit;       // (false for NaN)
 }
-// true when the conv of an h x w level runs on a split-fp16 kernel: those fuse the 2x2 pool of an encoder block's output into
-// their epilogue (ConvArgsH::pool_out)
+// the largest pixel count the batch statistics of a conv's sources ran over (0: no source is normalised by batch statistics)
+static double conv_stat_pixels(const ConvSrc& a, const ConvSrc& b) {
+    double n = 0.0;
+    if (a.bn.stat && a.bn.inv_n > 0.0) n = 1.0 / a.bn.inv_n;
+    if (b.C && b.bn.stat && b.bn.inv_n > 0.0 && 1.0 / b.bn.inv_n > n) n = 1.0 / b.bn.inv_n;
+    return n;
+}
+// true when the LAST conv of an encoder block at an h x w level (its input: the block's previous conv, statistics over h x w
+// pixels) runs on a split-fp16 kernel: those fuse the 2x2 pool of the block's output into their epilogue (ConvArgsH::pool_out)
 static bool conv_fuses_pool(const DenoiseState* s, bool batch, int H, int W) {
-    return s->opt_fused_pool && impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0);
+    return s->opt_fused_pool && impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix &&
+           f16_range_ok(s, batch, (double)H * (double)W, 65000.0);
 }
 
 // One conv layer: picks the kernel for the level (implementation, size, operand range), launches it and leaves in `dst` the raw
@@ -1780,6 +1795,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         return fail(ctx, AIPT_E_STATE, "layer %d: %d+%d input channels wired, %d+%d expected", li, A.C, expect - A.C, L.ca, L.cin - L.ca);
     long long* const stat = batch ? s->stat[s->sset] + (size_t)li * DenoiseState::STAT_LAYER : nullptr;
     g.stat = stat; g.sc = DenoiseState::STAT_SC;
+    const double nstat = conv_stat_pixels(g.a, g.b);       // what bounds the normalised inputs (f16_range_ok)
     const bool prof = ((s->prof_mask >> li) & 1u) && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;
     hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * NLAYERS + li) * 2] : nullptr;
 #ifdef AIPT_DEBUG_HOOKS
@@ -1798,7 +1814,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         hipLaunchKernelGGL(conv3x3_valu, dim3((W + 63) / 64, H, L.cout), dim3(64), 0, s->cur, g);
         if (batch)
             hipLaunchKernelGGL(channel_stats, dim3(L.cout), dim3(256), 0, s->cur, dst.p, (size_t)H * W, stat);
-    } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16 && f16_range_ok(s, batch, H / 2, W / 2, 65000.0)) {
+    } else if (L.d_wsplit_d2s && upA && g.b.C && impl_is_f16(s->impl) && 4 * L.cout <= 16 && f16_range_ok(s, batch, nstat, 65000.0)) {
         // upsample + conv with 3 outputs on the split-fp16 kernel: half-resolution conv, 12 virtual channels, depth-to-space store
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.a.up = 0; gh.b.up = 0;
@@ -1815,7 +1831,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const int r_wpg = s->num_cus / 8;
         if ((long long)gh.H * gh.W >= s->opt_r_minpix && gh.nchunks <= RR_MAXCH && r_wpg >= 1 && !(gh.H & 1) && !(gh.W & 1) && L.d_wsplit1_d2s[0] &&
             (long long)H * W * 16 < (1ll << 31) &&
-            f16_range_ok(s, batch, gh.H, gh.W, 4000.0)) {
+            f16_range_ok(s, batch, nstat, 4000.0)) {
             // the register-staged kernel: 16 virtual channels (4 x parity + channel) in its one group of 32
             gh.wsplit = L.d_wsplit1_d2s[w16_mode(s) ? 1 : 0]; gh.bias = L.d_bias32_d2s4;
             gh.cout = 16;
@@ -1851,7 +1867,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_quad<3,3,false>");
         if (batch) hipLaunchKernelGGL((conv3x3_quad<3, 3, true>), dim3(nblk), dim3(256), 0, s->cur, g);
         hipLaunchKernelGGL((conv3x3_quad<3, 3, false>), dim3(nblk), dim3(256), 0, s->cur, g);
-    } else if (impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0)) {
+    } else if (impl_is_f16(s->impl) && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, nstat, 65000.0)) {
         // split-fp16 MFMA
         ConvArgsH gh;
         gh.a = g.a; gh.b = g.b; gh.H = H; gh.W = W;
@@ -1876,7 +1892,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
         if ((long long)H * W >= s->opt_r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && !(H & 1) && !(W & 1) &&
             (long long)pad16(L.cout) * H * W * 4 < (1ll << 31) &&      // its output descriptors address the tensor with 31-bit offsets
-            (gh.a.planar || f16_range_ok(s, batch, H, W, 4000.0))) {
+            (gh.a.planar || f16_range_ok(s, batch, nstat, 4000.0))) {
             // planar input: the wide-range two-accumulator arithmetic on the hi + 2^11 lo slabs (see the kernel)
             gh.wsplit = gh.a.planar ? L.d_wsplit : w16 ? L.d_wsplit1_16 : L.d_wsplit1;
             gh.tiles_x = (W + RR_PX - 1) / RR_PX; gh.tiles_y = (H + 3) / 4; gh.groups = r_groups;
@@ -2167,7 +2183,9 @@ int aipt_denoise_configure(aipt_ctx* ctx, int height, int width) {
     auto mk = [&](Tensor& t, int C, int lvl) -> int {
         t.C = C; t.slope = SLOPE; t.planar = 0;
         // C4 layout, allocated up to a multiple of 16 channels: conv3x3_f16x3r fetches whole 16-channel chunks without clamping the
-        // quad index (the extra planes are never written; their BN coefficients are (0, 0))
+        // quad index.  Consumers give the extra planes BN coefficients (0, 0); the LDS-tiled kernels never write them, the
+        // register-staged kernel stores its pad quads there -- zeros, because pad weights and pad bias are exactly 0 and every
+        // operand is finite (the range checks of f16_range_ok and the clamp of the planar input see to that)
         const size_t bytes = sizeof(float) * (size_t)pad16(C) * (height >> lvl) * (width >> lvl);
         int rc = alloc(bytes, (void**)&t.p);
         if (rc) return rc;
@@ -2294,7 +2312,7 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
     // the G-buffer contract is planar [10][H][W] (pathtrace.cu:81-94).  The split-fp16 conv reads it as it is; the other
     // implementations get a C4 copy first.
     in = X.In; in.C = 10; in.slope = 1.0f; in.planar = 0;         // bn: identity
-    const bool direct = impl_is_f16(s->impl) && (long long)H * W >= s->opt_f16_minpix && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, H, W, 65000.0);
+    const bool direct = impl_is_f16(s->impl) && (long long)H * W >= s->opt_f16_minpix && (long long)H * W >= s->opt_small_minpix && f16_range_ok(s, batch, 0.0, 65000.0);   // an untransformed input: no statistics
     if (direct) {
         in.p = const_cast<float*>(d_in10); in.planar = 1;
     } else {

@@ -639,6 +639,7 @@ __device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur
 #ifndef AIPT_POOL_TAIL_BOTH
 #define AIPT_POOL_TAIL_BOTH 1
 #endif
+static_assert(!AIPT_POOL_TAIL_BOTH || AIPT_POOL_COOP_LEAF, "the both-kinds tail steps its leaves cooperatively: its LDS tables exist only with AIPT_POOL_COOP_LEAF");
 constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
 struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float2* rays; };   // this wave's LDS slices
 // inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)

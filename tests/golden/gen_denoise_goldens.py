@@ -17,7 +17,11 @@ ai_path_tracer_denoiser_amd/synth.py.  Stored per case: every output frame in fu
 the 6 hidden states after the last frame per-channel mean/mean-square (fp64) and 512 strided
 samples.
 
-Usage: python tests/golden/gen_denoise_goldens.py
+Round 5 -- cases at the sizes where the register-staged kernel `conv3x3_f16x3r` runs (selected from 200 000 pixels per level,
+include/aiptd.h AIPT_DN_OPT_R_MINPIX): one 384x640 frame stored in full (level 0 on that kernel) and one 736x1280 frame -- the
+benchmark size, levels 0 and 1 on it -- stored as 65 536 strided samples + per-channel fp64 mean / mean-square of the output.
+
+Usage: python tests/golden/gen_denoise_goldens.py [case-name ...]      (no names: all cases)
 """
 import os
 import sys
@@ -42,7 +46,10 @@ CASES = [
     ("r_carry_64",     64, 64,  565,  0, "running", 3),
     ("b_carry_96x160", 96, 160, 566,  1, "batch",   2),
     ("r_reset_96x160", 96, 160, 566,  1, "running", 1),
+    ("b_reset_384x640", 384, 640, 567, 2, "batch",  1),
+    ("b_reset_736x1280", 736, 1280, 568, 3, "batch", 1),      # stored as samples + moments (SAMPLED below)
 ]
+SAMPLED = {"b_reset_736x1280": 65536}
 
 
 def hidden_summary(h):
@@ -57,7 +64,10 @@ def hidden_summary(h):
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
     for name, H, W, wseed, iseed, bn, frames in CASES:
+        if only and name not in only:
+            continue
         params = synth.make_params(wseed)
         model = M.AutoEncoder(10)
         sd = {k: torch.from_numpy(np.array(v)) for k, v in arch.state_dict_from_params(params).items()}
@@ -79,6 +89,13 @@ def main():
                   model.encoder5[0], model.bottleneck]
         store = {"out": np.stack(outs).astype(np.float32),
                  "meta": np.array([H, W, wseed, iseed, frames, 1 if bn == "batch" else 0], np.int64)}
+        if name in SAMPLED:
+            o = store.pop("out")
+            flat = o.reshape(-1)
+            idx = np.linspace(0, flat.size - 1, SAMPLED[name]).astype(np.int64)
+            o64 = o.astype(np.float64).reshape(frames, 3, -1)
+            store.update(out_idx=idx, out_samples=flat[idx], out_mean=o64.mean(axis=2), out_msq=(o64 * o64).mean(axis=2),
+                         out_absmax=np.abs(o64).max(axis=2))
         for lvl, b in enumerate(blocks):
             m1, m2, smp, idx = hidden_summary(b.hidden[0].numpy())
             store[f"h{lvl}_mean"] = m1
@@ -87,8 +104,8 @@ def main():
             store[f"h{lvl}_idx"] = idx
         path = os.path.join(HERE, f"denoise_{name}.npz")
         np.savez_compressed(path, **store)
-        print(name, "out range", float(store["out"].min()), float(store["out"].max()),
-              os.path.getsize(path) // 1024, "KiB")
+        o = store["out"] if "out" in store else store["out_samples"]
+        print(name, "out range", float(o.min()), float(o.max()), os.path.getsize(path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

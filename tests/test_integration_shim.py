@@ -1,6 +1,12 @@
 """The reference-side binding INTEGRATION.md shows (tests/integration/pathtrace_shim.cpp: pathtraceInit / pathtrace /
 pathtraceFree over libaiptd.so) is real code: compiled and linked here against stand-ins for the reference's headers, and on a
-GPU box run through a miniature of the reference's host loop and compared with the oracle."""
+GPU box run through a miniature of the reference's host loop and compared with the oracle.
+
+Round 5: where /root/reference exists (the build container) the same shim is also compiled against the reference's REAL
+Inference/src/pathtrace.h / scene.h / sceneStructs.h (every static_assert of the shim holds against the real structs), and
+oracle/Makefile `ref` links it with the reference's own scene.cpp + utilities.cpp into oracle/_ref/shim_ref_host
+(tests/integration/ref_host_main.cpp): the reference's Scene class parses the scene file, the shim renders.  That prebuilt
+binary travels to the GPU box like our own .so files and is run there against the oracle."""
 import os
 import subprocess
 
@@ -12,6 +18,19 @@ from ai_path_tracer_denoiser_amd import synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HERE = os.path.join(ROOT, "tests", "integration")
 PKG = os.path.join(ROOT, "ai_path_tracer_denoiser_amd")
+
+
+REF = "/root/reference/Inference"
+REF_HOST = os.path.join(ROOT, "oracle", "_ref", "shim_ref_host")
+
+
+def _nvinc():
+    import site
+    for d in site.getsitepackages() + [site.getusersitepackages()]:
+        p = os.path.join(d, "triton", "backends", "nvidia", "include")
+        if os.path.exists(os.path.join(p, "cuda_runtime.h")):
+            return p
+    return None
 
 
 def _build(tmp_path):
@@ -38,6 +57,61 @@ def test_shim_compiles_and_links_against_the_c_abi(tmp_path):
     assert "tests/integration/pathtrace_shim.cpp" in doc
     for line in ("void pathtraceInit(Scene* scene) {", "void pathtrace(uchar4* /*pbo*/, int /*frame*/, int iter) {"):
         assert line in doc and line in open(os.path.join(HERE, "pathtrace_shim.cpp")).read()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "src", "pathtrace.h")) or _nvinc() is None,
+                    reason="needs /root/reference and the NVIDIA cuda_runtime.h (build container only)")
+def test_shim_compiles_against_the_reference_real_headers(tmp_path):
+    """pathtrace_shim.cpp against the reference's own pathtrace.h (:6-8), scene.h and sceneStructs.h (:15-97): -Wall -Werror
+    on the shim (the reference's and NVIDIA's headers come in as system headers), every static_assert on the struct layouts
+    holds; then the reference-tree host (its real Scene class + the shim + libaiptd.so) builds and fails loudly without a GPU"""
+    obj = str(tmp_path / "shim.o")
+    cmd = ["g++", "-O1", "-std=c++11", "-Wall", "-Werror", "-c", "-isystem", _nvinc(), "-isystem", os.path.join(REF, "external", "include"),
+           "-isystem", os.path.join(REF, "src"), "-I", os.path.join(ROOT, "include"), os.path.join(HERE, "pathtrace_shim.cpp"), "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout
+    for want in ("pathtraceInit(Scene*)", "pathtraceFree()", "pathtrace(uchar4*, int, int)"):
+        assert f" T {want}" in syms, syms                                   # the reference's three prototypes, defined
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref", "-s"], capture_output=True, text=True)
+    assert r.returncode == 0 and os.path.exists(REF_HOST), r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        w = tmp_path / "w.aiptw"
+        w.write_bytes(synth.make_blob(565))
+        r = subprocess.run([REF_HOST, os.path.join(ROOT, "scenes", "cornell.txt"), str(w), str(tmp_path / "o.f32"), "64", "64"],
+                           capture_output=True, text=True)
+        assert r.returncode != 0 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [(64, 64), (80, 48)])
+def test_reference_tree_host_runs_on_the_shim(tmp_path, res):
+    """oracle/_ref/shim_ref_host = the reference's OWN Scene(filename) (scene.cpp compiled where it lies) + main.cpp's camera
+    derivation + pathtraceInit / pathtrace / pathtraceFree of the shim over libaiptd.so: host_tensor bit-equal to the oracle,
+    denoised frame <= 1e-3.  The binary is built in the build container (`make -C oracle ref`) and travels with the snapshot."""
+    import oracle
+    if not os.path.exists(REF_HOST):
+        pytest.skip("oracle/_ref/shim_ref_host was not built (needs /root/reference at build time)")
+    w = tmp_path / "w.aiptw"
+    blob = synth.make_blob(565)
+    w.write_bytes(blob)
+    scene = os.path.join(ROOT, "scenes", "cornell.txt")
+    out = tmp_path / "o.f32"
+    r = subprocess.run([REF_HOST, scene, str(w), str(out), str(res[0]), str(res[1])], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    W, H = [int(v) for v in r.stdout.split()]
+    assert (W, H) == res
+    raw = np.fromfile(out, np.float32)
+    g, rgb = raw[:10 * W * H].reshape(10, H, W), raw[10 * W * H:].reshape(3, H, W)
+    sc = oracle.OracleScene.parse(scene, res=res)
+    g_ref, _, _ = sc.pathtrace()
+    assert np.array_equal(g.view(np.uint32), g_ref.view(np.uint32))
+    Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
+    gp = np.zeros((10, Hp, Wp), np.float32)
+    gp[:, :H, :W] = g_ref
+    y_ref = oracle.DenoiseOracle(blob, Hp, Wp).forward(gp, True, False)[:, :H, :W]
+    assert np.abs(rgb - y_ref).max() <= 1e-3
 
 
 @pytest.mark.gpu

@@ -42,6 +42,18 @@ def test_oracle_matches_reference_goldens(golden_dir, name):
                                    atol=2e-4 * max(1.0, np.abs(g[f"h{lvl}_samples"]).max()))
 
 
+def test_oracle_matches_the_reference_model_where_the_register_staged_kernel_runs(golden_dir):
+    """[r5] denoise_b_reset_384x640.npz: one full output frame of the imported reference model at a size whose level 0 the GPU
+    runs on conv3x3_f16x3r (>= 200 000 pixels).  (The 736x1280 case -- samples + moments -- is checked on the GPU box, where the
+    oracle's 140 GFLOP take a second instead of a minute: tests/test_gpu_denoise_kernels.py.)"""
+    g = np.load(os.path.join(golden_dir, "denoise_b_reset_384x640.npz"))
+    H, W, wseed, iseed, frames, batch = [int(v) for v in g["meta"]]
+    assert (H, W, frames, batch) == (384, 640, 1, 1)
+    y = DenoiseOracle(synth.make_blob(wseed), H, W).forward(synth.make_gbuffer(H, W, iseed, 0), bn_batch=True, carry=False)
+    err = np.abs(y - g["out"][0]).max()
+    assert err <= 1e-3, err
+
+
 def test_reset_equals_first_carry_frame():
     """forward(x, j=0) semantics: a carry call with no valid hidden state starts from zeros."""
     blob = synth.make_blob(7)

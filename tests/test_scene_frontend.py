@@ -116,3 +116,63 @@ def test_recompute_normals_flag(tmp_path):
         assert not np.allclose(n[0], np.array([list(p) for p in g.n], np.float32)[0], atol=1e-3)
     with pytest.raises(api.AiptError):
         api.Scene(str(scene), flags=4)
+
+
+# ------------------------------------------------------------------ pinned to the reference's own Scene class [r5]
+# tests/golden/scene_ref_dumps.npz holds what /root/reference/Inference/src/scene.cpp:11-320 (compiled unmodified, g++ -O0,
+# oracle/_ref/scene_dump) made of every scene file of the reference that its parser loads in the build container, of its
+# cube.obj mesh scenes fed a procedural cube, and of three procedural OBJ scenes; plus main.cpp:66-78's zoom / phi / theta
+# and the cameras of main.cpp:122-140 at six orbit offsets.
+from tests import ref_dumps  # noqa: E402
+
+REF_SCENES = ref_dumps.load_all()
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+@pytest.mark.parametrize("ref", REF_SCENES, ids=[r.name for r in REF_SCENES])
+def test_scene_load_equals_the_reference_scene_class(ref, tmp_path, monkeypatch):
+    path, cwd = ref.materialise(str(tmp_path))
+    monkeypatch.chdir(cwd)
+    s = api.Scene(os.path.relpath(path, cwd))
+    assert (s.ngeoms, s.nmaterials, s.nfaces, s.iterations, s.depth) == \
+        (ref.ngeoms, ref.nmaterials, ref.nfaces, ref.iterations, ref.depth)
+    for k, (a, b) in enumerate(zip(s.geoms, ref.geoms)):
+        assert bytes(a) == b, f"geom {k}"
+    for k, (a, b) in enumerate(zip(s.materials, ref.materials)):
+        assert bytes(a) == b, f"material {k}"
+    for k, (a, b) in enumerate(zip(s.faces, ref.faces)):
+        assert bytes(a) == b, f"face {k}"
+    if ref.nfaces:
+        assert bytes(s.mesh_box) == ref.mesh_box            # incl. the FLT_MIN start of ub (scene.cpp:216-218)
+    assert (_f32(s.zoom), _f32(s.phi), _f32(s.theta)) == (ref.zoom, ref.phi, ref.theta)
+    # the camera a loaded scene carries is the first frame's: runCuda()'s camchanged block at the loaded (zoom, phi, theta)
+    assert ref.orbits[0][:2] == (0, 0) and bytes(s.camera) == ref.orbits[0][2]
+    for dphi, dtheta, want in ref.orbits:
+        cam = s.orbit(phi=float(ref.phi + dphi), theta=float(ref.theta + dtheta))
+        assert bytes(cam) == want, f"orbit {dphi} {dtheta}"
+
+
+@pytest.mark.parametrize("ref", [r for r in REF_SCENES if r.nfaces == 0], ids=[r.name for r in REF_SCENES if r.nfaces == 0])
+def test_oracle_parser_equals_the_reference_scene_class(ref, tmp_path):
+    """the oracle's own reader of the grammar (oracle/__init__.py OracleScene.parse; primitives, materials, camera -- meshes
+    reach the oracle as arrays) against the same dumps"""
+    path, _ = ref.materialise(str(tmp_path))
+    o = oracle.OracleScene.parse(path)
+    assert (len(o.geoms), len(o.materials), o.iterations, o.depth) == (ref.ngeoms, ref.nmaterials, ref.iterations, ref.depth)
+    for k, (a, b) in enumerate(zip(o.geoms, ref.geoms)):
+        assert bytes(a) == b, f"geom {k}"
+    for k, (a, b) in enumerate(zip(o.materials, ref.materials)):
+        assert bytes(a) == b, f"material {k}"
+    assert (_f32(o.zoom), _f32(o.phi), _f32(o.theta)) == (ref.zoom, ref.phi, ref.theta)
+    for dphi, dtheta, want in ref.orbits:
+        o.set_orbit(o.zoom, float(ref.phi + dphi), float(ref.theta + dtheta))
+        assert bytes(o.camera) == want, f"orbit {dphi} {dtheta}"
+
+
+def test_the_reference_dump_set_is_what_the_header_says():
+    names = [r.name for r in REF_SCENES]
+    assert len(names) >= 40 and "Scenes/cornell.txt" in names and "Scenes/motion_blur.txt" in names
+    assert sum(r.nfaces > 0 for r in REF_SCENES) >= 6 and max(r.nfaces for r in REF_SCENES) >= 100

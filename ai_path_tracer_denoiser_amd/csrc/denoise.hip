@@ -1182,8 +1182,19 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                         // ((v - hi) 2^11 of an unclamped v is inf, and inf x 0 of a pad weight is NaN for the whole frame)
                         v0 = __builtin_amdgcn_fmed3f(v0, -65504.0f, 65504.0f); v1 = __builtin_amdgcn_fmed3f(v1, -65504.0f, 65504.0f);
                     }
-                    xh[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
-                    xl[p] = PLANAR ? split_lo_mix_scaled(xh[p], v0 * LO_SCALE, v1 * LO_SCALE, -LO_SCALE) : split_lo_mix(xh[p], v0, v1);
+                    if (PLANAR) {
+                        // hi rounded to NEAREST (v_cvt_pk_f16_f32): |v - hi| <= ulp / 2 <= 16, so the low half (v - hi) 2^11 stays
+                        // <= 32 768.  With the round-toward-zero pack the remainder reaches a whole ulp -- 32 above 32 768, i.e. for
+                        // |x| >= 2^19 -- and (v - hi) 2^11 >= 65 520 rounds to fp16 inf: one such pixel and the frame is NaN
+                        // (found in round 5 by feeding |x| up to 1.0e6, the range include/aiptd.h promises)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+                        xh[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){v0, v1}, f16x2v));
+                        xl[p] = split_lo_mix_scaled(xh[p], v0 * LO_SCALE, v1 * LO_SCALE, -LO_SCALE);
+                    } else {
+                        xh[p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v0, v1));
+                        xl[p] = split_lo_mix(xh[p], v0, v1);
+                    }
                     if (WC) { xh[p] = ok ? xh[p] : 0u; xl[p] = ok ? xl[p] : 0u; }
                 }
                 // ---- the ring slot is free: fetch PF rows ahead (into the next chunk / the next item when that wraps)

@@ -84,6 +84,11 @@ def parse_args(argv=None):
     ap.add_argument("--dn-opt", action="append", metavar="OPTION=VALUE", help="aipt_denoise_set_option(OPTION, VALUE): kernel-selection experiments")
     ap.add_argument("--gate-ms", type=float, default=0.0, help="diagnostic: queue the timed region behind a spin of this many ms (profiler timelines)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    # test hooks for the multi-rank branch on a ONE-GPU box (tests/test_gpu_bench_path.py): N ranks of this script share GPU 0
+    # and talk over gloo, so that init_process_group, the three broadcasts, all_reduce(MAX), the sharding self-check and the
+    # gathers run before an 8-GPU node runs them.  Refused when the node has a GPU per rank: the measured path is RCCL.
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--ranks-share-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline-events", action="store_true")
     ap.add_argument("--layers", action="store_true", help="print the per-conv-layer time table (stderr)")
     args = ap.parse_args(argv)
@@ -107,7 +112,7 @@ def respawn_if_needed(args):
         return
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not args.ranks_share_gpu:
         sys.exit(f"bench.py: --gpus {args.gpus} requested but this node exposes {have} GPU(s); refusing to run fewer ranks "
                  f"and report them as {args.gpus}")
     import socket
@@ -152,9 +157,10 @@ class Workload:
     """Everything bench.py sets up before its timed region, and the calls the timed region makes.  tests/test_gpu_bench_path.py
     builds the same object, so the parity tests check the path -- and the sizes -- that are timed here."""
 
-    def __init__(self, args, rank=0, world=1, local_rank=0, like=None, batch=None):
+    def __init__(self, args, rank=0, world=1, local_rank=0, like=None, batch=None, coll_dev=None):
         """like: another Workload whose scene / weight blobs and cameras are reused (no second BVH build, no broadcast);
-        batch: override args.batch (1 = a frame-by-frame context: aipt_frame only)"""
+        batch: override args.batch (1 = a frame-by-frame context: aipt_frame only); coll_dev: device of the broadcast buffers
+        (default: this rank's GPU -- RCCL; the CPU under the gloo test hook)"""
         import numpy as np
         import torch
         from ai_path_tracer_denoiser_amd import api, synth
@@ -176,10 +182,11 @@ class Workload:
                 scene_blob, cam_bytes, desc = build_scene(args, api, synth)
                 weight_blob = synth.make_blob(565)
                 desc_b = desc.encode()
-            self.scene_blob = adist.broadcast_bytes(scene_blob, 0, self.dev)
-            self.weight_blob = adist.broadcast_bytes(weight_blob, 0, self.dev)
-            cam_bytes = adist.broadcast_bytes(cam_bytes, 0, self.dev)
-            self.desc = adist.broadcast_bytes(desc_b, 0, self.dev).decode()
+            cdev = self.dev if coll_dev is None else coll_dev
+            self.scene_blob = adist.broadcast_bytes(scene_blob, 0, cdev)
+            self.weight_blob = adist.broadcast_bytes(weight_blob, 0, cdev)
+            cam_bytes = adist.broadcast_bytes(cam_bytes, 0, cdev)
+            self.desc = adist.broadcast_bytes(desc_b, 0, cdev).decode()
             self.cam0 = api.Camera.from_buffer_copy(cam_bytes[:84])
             self.zoom, self.phi0, self.theta = [float(v) for v in np.frombuffer(cam_bytes[84:], np.float32)]
         ctx = self.ctx
@@ -269,16 +276,28 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    shared = False
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if torch.cuda.device_count() <= local_rank:
-            sys.exit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.ranks_share_gpu or args.backend != "nccl":
+            # the test hook: every rank on GPU 0, collectives over gloo on host tensors (RCCL needs a GPU per rank)
+            if not (args.ranks_share_gpu and args.backend == "gloo"):
+                sys.exit("bench.py: --ranks-share-gpu and --backend gloo go together (a test hook for one-GPU boxes)")
+            if torch.cuda.device_count() >= world:
+                sys.exit(f"bench.py: this node has {torch.cuda.device_count()} GPUs for {world} ranks; --ranks-share-gpu is refused "
+                         "where every rank can have its own GPU (the measured path is one rank per GPU over RCCL)")
+            shared, local_rank = True, 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            if torch.cuda.device_count() <= local_rank:
+                sys.exit(f"bench.py: rank {rank} has no GPU {local_rank} ({torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cpu") if shared else torch.device("cuda", local_rank)    # where collective buffers live
 
-    wl = Workload(args, rank, world, local_rank)
+    wl = Workload(args, rank, world, local_rank, coll_dev=coll_dev)
     ctx, dev, W, H, depth, B = wl.ctx, wl.dev, wl.W, wl.H, wl.depth, wl.B
     outs, bn_batch, carry, trace_flags = wl.outs, wl.bn_batch, wl.carry, wl.trace_flags
     scene_blob, weight_blob, desc = wl.scene_blob, wl.weight_blob, wl.desc
@@ -349,7 +368,7 @@ def main():
     t1 = time.perf_counter()
     elapsed_local = elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     n_live = ctx.live_counts(depth)            # of the last trace call (all frames of its batch together)
@@ -430,8 +449,8 @@ def main():
                 got[k] = adist.checksum64(fb.outs[0])
         fb.run_frame_by_frame(cs, fb.outs[0], on_frame=on_frame)
         return [got[0], got[len(cs) - 1]]
-    sharded_ok, sharded_per_rank = adist.sharded_equals_single(local_sums, rerender, dev, rank)
-    per_rank_fps = adist.gather_int64([int(round(1e3 * args.steps / elapsed_local))], dev)
+    sharded_ok, sharded_per_rank = adist.sharded_equals_single(local_sums, rerender, coll_dev, rank)
+    per_rank_fps = adist.gather_int64([int(round(1e3 * args.steps / elapsed_local))], coll_dev)
 
     # the trace / denoise split: one un-pipelined frame
     ctx.sync()
@@ -588,7 +607,8 @@ def main():
                                    "zero hidden state; the last timed frame's G-buffer and denoised output must equal it bit for bit "
                                    "(the hidden state carries every earlier frame into it); the prefetching frame-by-frame run likewise",
                            "gbuffer_equal": gbuf_equal, "denoised_equal": out_equal},
-            "rccl_ranks": world, "sharded_equals_single": sharded_ok,
+            "rccl_ranks": 0 if shared else world, "sharded_equals_single": sharded_ok,
+            **({"ranks_share_gpu": True, "collectives": "gloo (test hook: every rank on GPU 0; not a scaling measurement)"} if shared else {}),
             "sharding_check": {"per_rank_equal": sharded_per_rank,
                                "per_rank_frames_per_s": [round(v[0] / 1e3, 3) for v in per_rank_fps],
                                "what": "checksums (8 bytes each, one all-gather) of every rank's first and last denoised frame against "

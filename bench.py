@@ -22,7 +22,7 @@ carried through the batch.  --batch 1 is the frame-by-frame sequence.  The trace
 measured on one single frame after the timed region.
 
 Prints ONE JSON line on rank 0.  Extra objects: "roofline" for the kernel that dominates THIS workload (HIP events on the
-launch stream inside the timed region; the runner-up kernel under "roofline_other"), "cpu_baseline" (the CPU oracle timed
+launch stream, on an untimed second pass over the timed region's frames; the runner-up kernel under "roofline_other"), "cpu_baseline" (the CPU oracle timed
 on the host cores, N=1 only), "frame" (ms split and the whole-frame HBM fraction).
 """
 import argparse
@@ -340,19 +340,11 @@ def main():
         prof_layers = by_kernel[conv_dominant]
     barrier()
 
-    # ---- timed region: exactly K frames
-    # HIP-event pairs around the launches of the dominant conv kernel and of the bounce kernel, on the launch stream, on the
-    # first frame of every batch of 16+ frames of the timed region (smaller batches: every third; frame by frame: every 4th frame).  The library runs a timed forward pass ALONE (the
-    # other denoiser stream drains before it and resumes after it), so a pair brackets the kernel and not its overlap with
-    # the next frame's launches; that costs the first two frames of those batches their overlap (~2 % of `value`).
-    PROF_EVERY = B if B >= 16 else 3 * B if B >= 4 else 4
+    # ---- timed region: exactly K frames, NO events in it and both denoiser streams live.  (Rounds 1-4 recorded the roofline's
+    # HIP-event pairs inside the timed region; a forward pass whose launches are timed runs ALONE -- the other denoiser stream
+    # drains before it -- which cost `value` about 2 %.)  The pairs are now taken on a second, untimed pass over the same K
+    # frames right after the timed region: same calls, same frames per trace launch set.
     timed_trace_calls = wl.trace_call_sizes(args.warmup, per_rank)
-    if prof_layers:
-        nrec = (args.steps + PROF_EVERY - 1) // PROF_EVERY
-        ctx.profile_stride(PROF_EVERY)
-        ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
-        # batched: every trace call of the timed region is recorded; frame by frame: every 4th
-        ctx.trace_profile_begin(nrec if B == 1 else len(timed_trace_calls), PROF_EVERY if B == 1 else 1)
     barrier()
     if args.gate_ms > 0:
         # diagnostic (rocprofv3 timelines): the timed call queues up behind a spin on the context's stream, so that the GPU starts it
@@ -375,13 +367,6 @@ def main():
     trace_kernels = [ctx.trace_kernel_name(0), ctx.trace_kernel_name(1)] if depth > 1 else [ctx.trace_kernel_name(0)] * 2
     P = W * H
     Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
-    # ---- the event recordings are closed BEFORE anything else runs, so that they hold the timed region's launches only
-    conv_prof = trace_prof = None
-    if prof_layers:
-        conv_prof = ctx.profile_end()
-        fr_calls, ms_calls = ctx.trace_profile_calls(depth)
-        ctx.trace_profile_end(depth)
-        trace_prof = (fr_calls, ms_calls)
     # what the timed region left behind: the last denoised frame and its G-buffer, and the first frame of this rank's chunk
     ctx.sync()
     last_nb = (per_rank - args.warmup - 1) % B + 1 if B > 1 else 1     # frames of the last call of the timed region
@@ -389,6 +374,22 @@ def main():
     gptr, grows, gstride = ctx.gbuffer()
     timed_gbuf = np.empty((10, grows, gstride), np.float32)
     assert api.lib().aipt_download(ctx._h, timed_gbuf.ctypes.data, gptr, timed_gbuf.nbytes) == 0
+    # ---- roofline pass (untimed): the K frames of the timed region again, with HIP-event pairs on the launch stream around the
+    # launches of the dominant conv kernel in EVERY frame (the library runs a forward pass whose launches are timed ALONE, so a
+    # pair brackets the kernel and not its overlap with the next frame's launches) and around every bounce launch.
+    conv_prof = trace_prof = None
+    if prof_layers:
+        nrec = min(args.steps, 4096)
+        ctx.profile_stride(1)
+        ctx.profile_begin(sum(1 << l for l in prof_layers), nrec)
+        ctx.trace_profile_begin(nrec if B == 1 else len(timed_trace_calls), 1)
+        run_frames(args.warmup, per_rank)
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        conv_prof = ctx.profile_end()
+        fr_calls, ms_calls = ctx.trace_profile_calls(depth)
+        ctx.trace_profile_end(depth)
+        trace_prof = (fr_calls, ms_calls)
 
     # ---- validation, outside the timed region: the whole sequence of this rank again, frame by frame (aipt_frame: one trace and
     # one denoiser pass at a time, no batching, no second stream) from a zero hidden state.  The last frame depends on every
@@ -509,10 +510,12 @@ def main():
                      "kernel": conv_dominant, "launches_per_frame": len(prof_layers), "avg_launch_ms": round(avg_ms, 5),
                      "ms_per_frame": round(avg_ms * len(prof_layers), 4),
                      "launches_timed": launches,
-                     "timing_note": ("the kernel ALONE: a timed forward pass runs with the other denoiser stream drained; in the "
-                                     "other frames two forward passes overlap, and rocprofv3's per-launch durations of the same "
+                     "timing_note": ("HIP-event pairs on the launch stream, taken on a second UNTIMED pass over the same K frames right "
+                                     "after the timed region (the timed region itself records no events).  The kernel ALONE: a "
+                                     "forward pass whose launches are timed runs with the other denoiser stream drained; in the "
+                                     "timed region two forward passes overlap, and rocprofv3's per-launch durations of the same "
                                      "command include that overlap (profiles/: kernel_stats vs kernel_stats_one_denoiser_stream)"
-                                     if B > 1 else "frame by frame: one stream"),
+                                     if B > 1 else "frame by frame: one stream; event pairs on an untimed second pass over the same frames"),
                      "algorithmic_bytes_per_launch": bytes_per_frame / len(prof_layers),
                      "flops_per_launch": flops_per_frame / len(prof_layers),
                      "arithmetic_intensity_flop_per_byte": round(ai, 1), "mfma": mfma, "hbm": hbm,
@@ -547,6 +550,7 @@ def main():
                        "kernel": name, "launches_per_frame": round(len(late) / fpc, 3), "avg_launch_ms": round(t_late / len(late), 5),
                        "ms_per_frame": round(t_late / fpc, 4), "frames_per_launch": fpc, "launches_timed": nsel * len(late),
                        "trace_calls_of_the_timed_region": [int(v) for v in fr_calls],
+                       "timing_note": "HIP-event pairs around every bounce launch of a second, untimed pass over the timed region's frames",
                        "algorithmic_bytes_per_launch": by_late / len(late),
                        "byte_model": "SURVEY 8d: sum over bounces of N_b x 160 B (44 B state read + 44 B write, 36 B hit record "
                                      "write + read of the reference's layout); BVH and triangle fetches are overhead, not algorithmic",

@@ -24,6 +24,16 @@
  * No C++ exception crosses this boundary.  One context per GPU and per host thread; all work is enqueued on the
  * context's HIP stream and is asynchronous unless stated otherwise.  Pointers named d_* are device pointers.
  * There is no CPU fallback: without a usable HIP device aipt_create fails.
+ *
+ * Environment variables the release library reads -- SCHEDULING only: each changes which launches share the chip or how many
+ * frames one set of launches covers, never a bit of any result (tests/test_gpu_frame.py, tests/test_cli.py compare them):
+ *   AIPT_DN_PIPELINE=0          aipt_frames: the denoiser passes of a call on ONE stream instead of two (profiling: a chip-wide
+ *                               counter then belongs to one kernel; tools/collect_evidence.sh)
+ *   AIPT_TRACE_POOL=0 / 1       batched traces: never / always pool the BVH walks of a workgroup's paths (default: from 4 frames
+ *                               per launch on)
+ *   AIPT_PREFETCH_TRACE_CUS=n   aipt_frame_prefetch: CUs of the trace stream's mask (default: half of the chip)
+ * Everything else (kernel selection, tile sizes) is an explicit ABI option (aipt_denoise_set_option) or a debug-build hook
+ * behind -DAIPT_DEBUG_HOOKS; tests/test_shipped_kernels_cpu.py fails on any other getenv in the kernels' sources.
  */
 #ifndef AIPTD_H
 #define AIPTD_H

@@ -80,6 +80,9 @@ void aipt_destroy(aipt_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (hipStream_t ps : ctx->pipe) if (ps) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
     for (hipStream_t ps : {ctx->st_trace, ctx->st_dn}) if (ps && ps != ctx->stream) { hipStreamSynchronize(ps); hipStreamDestroy(ps); }
+    if (ctx->st_lane1) { hipStreamSynchronize(ctx->st_lane1); hipStreamDestroy(ctx->st_lane1); }
+    if (ctx->ev_lane_fork) hipEventDestroy(ctx->ev_lane_fork);
+    if (ctx->ev_lane_join) hipEventDestroy(ctx->ev_lane_join);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     for (hipEvent_t ev : ctx->ev_join) if (ev) hipEventDestroy(ev);
     aipt::trace_destroy(ctx);
@@ -274,7 +277,8 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch) {
     if (batch < 1 || batch > AIPT_FRAMES_MAX) return fail(ctx, AIPT_E_INVALID, "aipt_frames_configure: batch %d (1..%d)", batch, AIPT_FRAMES_MAX);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
-    const int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch < AIPT_TRACE_BATCH_MAX ? batch : AIPT_TRACE_BATCH_MAX);
+    int rc = aipt_trace_configure_batch(ctx, ctx->fw, ctx->fh, batch < AIPT_TRACE_BATCH_MAX ? batch : AIPT_TRACE_BATCH_MAX);
+    if (!rc) rc = aipt::trace_enable_lanes(ctx);
     if (rc) return rc;
     for (float*& g : ctx->d_gbatches) if (g) { hipFree(g); g = nullptr; }
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
@@ -300,10 +304,35 @@ static int trace_frames(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cams, 
     // as few calls as AIPT_TRACE_BATCH_MAX allows, of (nearly) equal size: 20 frames are traced 10 + 10, not 16 + 4 (the
     // pooled walks of a 4-frame call refill their lanes from a quarter of the rays)
     const int ncalls = (nframes + AIPT_TRACE_BATCH_MAX - 1) / AIPT_TRACE_BATCH_MAX;
+    // [r5] Two lanes: from AIPT_TRACE_LANES_MIN (2) frames on, the two halves of a call's frames are traced BESIDE each other -- the
+    // first on `st`, the second on a side stream with its own path state.  A bounce launch lasts at least as long as its longest
+    // ray's chain of dependent node visits (~0.15 ms whatever the ray count: seven such floors per trace), and two launch
+    // sequences side by side fill each other's tails: 0.333 vs 0.382 ms per frame at 20 frames, 0.326 vs 0.387 at 24
+    // (tools/dual_trace_probe.py); calls of 2 / 4 / 8 frames: 718 / 813 / 887 against 668 / 756 / 804 frames/s.  Frames are independent, so the split changes no bit (tests/test_gpu_frame.py).
+    // AIPT_TRACE_LANES=1 keeps one lane (scheduling only; profiling passes that want one kernel at a time).
+    static const int lanes_env = getenv("AIPT_TRACE_LANES") ? atoi(getenv("AIPT_TRACE_LANES")) : 2;
     for (int c = 0, k = 0; c < ncalls; c++) {
         const int nb = nframes / ncalls + (c < nframes % ncalls ? 1 : 0);
-        const int rc = aipt::trace_on_stream(ctx, st, cams + k, nb, iter, depth, trace_flags, d_gbatch + k * frame, ctx->fhp, ctx->fwp, frame);
+        // (one lane while aipt_trace_profile_* records: an event pair then brackets a launch that has the chip to itself)
+        const int na_two = (nb + 1) / 2;
+        const bool two = lanes_env >= 2 && nb >= AIPT_TRACE_LANES_MIN && iter == 1 && !aipt::trace_profiling(ctx) &&
+                         aipt::trace_lanes_ready(ctx, nb - na_two);
+        const int na = two ? na_two : nb;
+        if (two) {
+            // the side lane starts where `st` stands now (the G-buffers it writes were last read by work queued on `st`) ...
+            AIPT_HIP(ctx, hipEventRecord(ctx->ev_lane_fork, st));
+            AIPT_HIP(ctx, hipStreamWaitEvent(ctx->st_lane1, ctx->ev_lane_fork, 0));
+        }
+        int rc = aipt::trace_on_stream(ctx, st, cams + k, na, iter, depth, trace_flags, d_gbatch + k * frame, ctx->fhp, ctx->fwp, frame);
         if (rc) return rc;
+        if (two) {
+            rc = aipt::trace_on_stream(ctx, ctx->st_lane1, cams + k + na, nb - na, iter, depth, trace_flags, d_gbatch + (k + na) * frame,
+                                       ctx->fhp, ctx->fwp, frame, 1);
+            if (rc) return rc;
+            // ... and `st` goes on when both halves are done
+            AIPT_HIP(ctx, hipEventRecord(ctx->ev_lane_join, ctx->st_lane1));
+            AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_lane_join, 0));
+        }
         k += nb;
     }
     return AIPT_OK;

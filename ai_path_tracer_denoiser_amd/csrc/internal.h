@@ -22,6 +22,7 @@ struct DenoiseState;   // denoise.hip
 // 4 streams 1.37x the throughput of one, tools/overlap_probe.py; ONE sequence, level by level behind each other: 3 in flight = 2 in flight)
 constexpr int AIPT_DN_PIPE = 2;
 constexpr int AIPT_TRACE_BATCH_MAX = 24;    // frames one set of trace launches can hold (= BMAX of trace.hip)
+constexpr int AIPT_TRACE_LANES_MIN = 2;     // aipt_frames: from this many frames on a trace call runs as two half-batches side by side
 constexpr int AIPT_FRAMES_MAX = 32;         // frames one aipt_frames call can hold
 
 struct aipt_ctx {
@@ -44,6 +45,8 @@ struct aipt_ctx {
     // `st_dn` -- two streams restricted to DISJOINT sets of CUs (hipExtStreamCreateWithCUMask): a scheduling choice (a single
     // frame's trace does not fill the chip; sharing all CUs measured slower), no longer a correctness fence
     hipStream_t st_trace = nullptr, st_dn = nullptr;
+    hipStream_t st_lane1 = nullptr;                   // aipt_frames: the second half of a call's frames is traced here, beside the first
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
     // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
     // pipelined): AIPT_DN_PIPE frames in flight
     hipStream_t pipe[AIPT_DN_PIPE - 1] = {};
@@ -107,7 +110,7 @@ int build_bvh4(const aipt_face* faces, int nfaces, std::vector<Bvh4Node>& nodes,
 // aipt_trace on an explicit stream; orders itself after the previous trace when that ran on another stream
 // (nframes > 1: a batch of frames traced by one set of launches, G-buffer f at d_gbuf + f * gbuf_frame floats)
 int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int nframes, int iter, int depth, uint32_t flags,
-                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame);
+                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame, int lane = 0);
 // wait for the main stream and the denoiser pipeline streams
 inline hipError_t sync_streams(aipt_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
@@ -115,12 +118,16 @@ inline hipError_t sync_streams(aipt_ctx* ctx) {
         if (e == hipSuccess && ps) e = hipStreamSynchronize(ps);
     if (e == hipSuccess && ctx->st_trace && ctx->st_trace != ctx->stream) e = hipStreamSynchronize(ctx->st_trace);
     if (e == hipSuccess && ctx->st_dn) e = hipStreamSynchronize(ctx->st_dn);
+    if (e == hipSuccess && ctx->st_lane1) e = hipStreamSynchronize(ctx->st_lane1);
     return e;
 }
 // aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)
 int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined = false,
                 hipStream_t on = nullptr);
 void trace_destroy(aipt_ctx* ctx);
+int trace_enable_lanes(aipt_ctx* ctx);        // aipt_frames_configure: allocate the side lane of two-lane traces and warm its stream
+bool trace_lanes_ready(aipt_ctx* ctx, int nframes);
+bool trace_profiling(aipt_ctx* ctx);          // aipt_trace_profile_begin is recording: traces run one lane at a time
 void denoise_destroy(aipt_ctx* ctx);
 
 }  // namespace aipt

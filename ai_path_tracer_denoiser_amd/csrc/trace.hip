@@ -87,6 +87,13 @@ struct TraceState {
     std::vector<hipEvent_t> prof_ev;              // [call][bounce][2]
     std::vector<int> prof_frames;                 // [call] frames the recorded call held
     char kname[2][40] = {};                       // instantiation that ran bounce 0 / the later bounces in the last trace
+    // Second LANE of per-path buffers (lane 1 of trace_on_stream): aipt_frames traces the two halves of a call's frames BESIDE
+    // each other on two streams (a bounce launch lasts at least as long as its longest ray's chain of dependent node visits,
+    // ~0.15 ms whatever the ray count; two launch sequences side by side hide each other's floors).  The lane shares the scene
+    // (pointers copied at every trace) and owns only its path state, sized for half of the batch.
+    TraceState* side = nullptr;
+    bool is_side = false;
+    bool side_used = false;                       // the last trace of this lane was followed by one on the side lane (a two-lane call)
 };
 
 struct TraceParams {
@@ -1388,9 +1395,17 @@ static void free_trace_profile(TraceState* s) {
     s->prof_max = 0; s->prof_calls = 0; s->prof_seen = 0;
 }
 
+static void free_side(TraceState* s) {
+    if (!s->side) return;
+    free_frame(s->side);                        // (the scene pointers of a side lane are borrowed)
+    delete s->side;
+    s->side = nullptr;
+}
+
 void trace_destroy(aipt_ctx* ctx) {
     TraceState* s = ctx->trace;
     if (!s) return;
+    free_side(s);
     free_scene(s);
     free_frame(s);
     free_trace_profile(s);
@@ -1600,13 +1615,9 @@ int aipt_scene_free(aipt_ctx* ctx) {
     return AIPT_OK;
 }
 
-int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) {
-    AIPT_CHECK_CTX(ctx);
-    if (width <= 0 || height <= 0 || batch < 1 || batch > BMAX || (long)width * height * batch > (1l << 30))
-        return fail(ctx, AIPT_E_INVALID, "aipt_trace_configure: %dx%d x %d frames (1..%d)", width, height, batch, BMAX);
-    AIPT_HIP(ctx, hipSetDevice(ctx->device));
-    AIPT_HIP(ctx, aipt::sync_streams(ctx));
-    TraceState* s = tstate(ctx);
+__global__ void trace_scan_warm(int* p) { if (threadIdx.x == 1000) p[0] = 0; }     // first submission to the side lane's stream
+
+static int configure_state(aipt_ctx* ctx, TraceState* s, int width, int height, int batch) {
     if (s->W == width && s->H == height && s->batch == batch && s->d_state) return AIPT_OK;
     free_frame(s);
     const int P = width * height;
@@ -1632,6 +1643,41 @@ int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) 
     return AIPT_OK;
 }
 
+int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch) {
+    AIPT_CHECK_CTX(ctx);
+    if (width <= 0 || height <= 0 || batch < 1 || batch > BMAX || (long)width * height * batch > (1l << 30))
+        return fail(ctx, AIPT_E_INVALID, "aipt_trace_configure: %dx%d x %d frames (1..%d)", width, height, batch, BMAX);
+    AIPT_HIP(ctx, hipSetDevice(ctx->device));
+    AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    TraceState* s = tstate(ctx);
+    if (s->side && (s->W != width || s->H != height || s->batch != batch)) free_side(s);
+    return configure_state(ctx, s, width, height, batch);
+}
+
+extern "C++" { namespace aipt {
+// aipt_frames_configure: the second lane of aipt_frames' two-lane traces, allocated here and not inside somebody's timed frame
+int trace_enable_lanes(aipt_ctx* ctx) {
+    TraceState* s = tstate(ctx);
+    if (!s->d_state || s->batch < AIPT_TRACE_LANES_MIN) return AIPT_OK;
+    if (!s->side) { s->side = new TraceState(); s->side->is_side = true; }
+    const int rc2 = configure_state(ctx, s->side, s->W, s->H, (s->batch + 1) / 2);
+    if (rc2) return rc2;
+    // ... together with its stream, which is made to run something now: the first submission to a new HIP stream sets up its
+    // hardware queue (milliseconds -- measured inside a timed 20-frame call: 715 instead of 905 frames/s)
+    if (!ctx->st_lane1) {
+        AIPT_HIP(ctx, hipStreamCreateWithFlags(&ctx->st_lane1, hipStreamNonBlocking));
+        AIPT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming));
+        AIPT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_lane_join, hipEventDisableTiming));
+    }
+    AIPT_HIP(ctx, hipMemsetAsync(s->side->d_nlive, 0, sizeof(int) * (MAX_DEPTH + 1), ctx->st_lane1));
+    hipLaunchKernelGGL(trace_scan_warm, dim3(1), dim3(64), 0, ctx->st_lane1, s->side->d_nlive);
+    AIPT_HIP(ctx, hipEventRecord(ctx->ev_lane_join, ctx->st_lane1));
+    AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join, 0));
+    AIPT_HIP(ctx, hipStreamSynchronize(ctx->st_lane1));
+    return AIPT_OK;
+}
+} }
+
 int aipt_trace_configure(aipt_ctx* ctx, int width, int height) { return aipt_trace_configure_batch(ctx, width, height, 1); }
 
 int aipt_trace_batch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t flags,
@@ -1649,10 +1695,22 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
 extern "C++" {
 namespace aipt {
 int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int nframes, int iter, int depth, uint32_t flags,
-                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame) {
+                    float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame, int lane) {
     TraceState* s = tstate(ctx);
     if (!s->have_scene) return fail(ctx, AIPT_E_STATE, "aipt_trace: no scene uploaded");
     if (!s->d_state) return fail(ctx, AIPT_E_STATE, "aipt_trace: call aipt_trace_configure first");
+    if (lane) {
+        // lane 1: its own path state (half of the batch), the main lane's scene.  Always on the SAME side stream, which orders
+        // its traces among themselves; the caller orders it against everything else (trace_frames in abi.cpp)
+        TraceState* m = s;
+        TraceState* d = m->side;
+        if (!d || !d->d_state || d->W != m->W || d->H != m->H) return fail(ctx, AIPT_E_STATE, "aipt_trace: the side lane is not configured");
+        d->d_geoms = m->d_geoms; d->ngeoms = m->ngeoms; d->d_mats = m->d_mats; d->nmats = m->nmats;
+        d->d_faces = m->d_faces; d->nfaces = m->nfaces; d->stack_need = m->stack_need;
+        d->d_nodes = m->d_nodes; d->nnodes = m->nnodes; d->d_tris = m->d_tris; d->d_lfaces = m->d_lfaces;
+        d->box = m->box; d->have_scene = true;
+        s = d;
+    }
     if (!cam || !d_gbuf) return fail(ctx, AIPT_E_INVALID, "aipt_trace: NULL argument");
     if (nframes < 1 || nframes > s->batch)
         return fail(ctx, AIPT_E_INVALID, "aipt_trace: %d frames, configured for %d (aipt_trace_configure_batch)", nframes, s->batch);
@@ -1689,13 +1747,17 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         }
     }
     const int ovf_need = s->nfaces && s->stack_need > STACK_LDS ? s->stack_need - STACK_LDS : 0;
-    if (ovf_need > s->ovf_entries) {
+    // (every trace of the main lane also sizes the side lane's overflow area, so that a call's first two-lane trace does not
+    // allocate -- and synchronise -- inside somebody's timed frames)
+    for (TraceState* t : {s, !lane && s->side && s->side->d_state ? s->side : (TraceState*)nullptr}) {
+        if (!t || ovf_need <= t->ovf_entries) continue;
         AIPT_HIP(ctx, hipStreamSynchronize(st));
-        hipFree(s->d_stack_ovf); s->d_stack_ovf = nullptr; s->ovf_entries = 0;
-        AIPT_HIP(ctx, hipMalloc((void**)&s->d_stack_ovf, sizeof(int) * (size_t)ovf_need * s->P * s->batch));
-        s->ovf_entries = ovf_need;
+        if (t != s && ctx->st_lane1) AIPT_HIP(ctx, hipStreamSynchronize(ctx->st_lane1));
+        hipFree(t->d_stack_ovf); t->d_stack_ovf = nullptr; t->ovf_entries = 0;
+        AIPT_HIP(ctx, hipMalloc((void**)&t->d_stack_ovf, sizeof(int) * (size_t)ovf_need * t->P * t->batch));
+        t->ovf_entries = ovf_need;
     }
-    if (ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
+    if (!lane && ctx->last_trace_stream && ctx->last_trace_stream != st) AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
     if (blur && !(iter % 4) && iter < 3000) {                   // moveGeom, pathtrace.cu:442-446 (dt = 0.10)
         bool moved = false;
         for (aipt_geom& g : s->h_geoms) {
@@ -1782,8 +1844,11 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         s->prof_seen++;
     }
     AIPT_HIP(ctx, hipGetLastError());
-    AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
-    ctx->last_trace_stream = st;
+    if (!lane) {
+        AIPT_HIP(ctx, hipEventRecord(ctx->ev_traced, st));
+        ctx->last_trace_stream = st;
+    }
+    if (lane) tstate(ctx)->side_used = true; else s->side_used = false;
     s->last_depth = depth;
     s->last_frames = nframes;
     s->mat0_valid = p.mat0 != nullptr;
@@ -1840,6 +1905,14 @@ int aipt_trace_profile_calls(aipt_ctx* ctx, int* nframes_per_call, double* ms_pe
     return AIPT_OK;
 }
 
+extern "C++" { namespace aipt {
+bool trace_profiling(aipt_ctx* ctx) { return ctx->trace && ctx->trace->prof_max > 0; }
+bool trace_lanes_ready(aipt_ctx* ctx, int nframes) {
+    const TraceState* s = ctx->trace;
+    return s && s->side && s->side->d_state && s->side->W == s->W && s->side->H == s->H && nframes <= s->side->batch && ctx->st_lane1;
+}
+} }
+
 int aipt_trace_kernel_name(aipt_ctx* ctx, int bounce, char* kernel, size_t kernel_len) {
     AIPT_CHECK_CTX(ctx);
     TraceState* s = tstate(ctx);
@@ -1884,8 +1957,17 @@ int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n)
     AIPT_CHECK_CTX(ctx);
     TraceState* s = tstate(ctx);
     if (!s->d_nlive || !s->last_depth) return fail(ctx, AIPT_E_STATE, "aipt_trace_live_counts_frame: no trace has run");
+    // a two-lane call (aipt_frames): its second half was traced on the side lane; frames count through both halves
+    if (s->side_used && s->side && frame >= s->last_frames) { frame -= s->last_frames; s = s->side; }
     if (!h_n_live || n < 1 || frame < 0 || frame >= s->last_frames) return fail(ctx, AIPT_E_INVALID, "aipt_trace_live_counts_frame: bad arguments");
-    if (s->last_frames == 1) return aipt_trace_live_counts(ctx, h_n_live, n);
+    if (s->last_frames == 1 && !s->is_side) return aipt_trace_live_counts(ctx, h_n_live, n);
+    if (s->last_frames == 1) {                     // a one-frame side lane keeps totals only
+        std::vector<int> one(MAX_DEPTH + 1);
+        AIPT_HIP(ctx, aipt::sync_streams(ctx));
+        AIPT_HIP(ctx, hipMemcpy(one.data(), s->d_nlive, sizeof(int) * (MAX_DEPTH + 1), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++) h_n_live[i] = i == 0 ? s->P : (i <= s->last_depth ? one[i] : 0);
+        return AIPT_OK;
+    }
     std::vector<int> tmp((MAX_DEPTH + 1) * BMAX);
     if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
     AIPT_HIP(ctx, hipMemcpyAsync(tmp.data(), s->d_nlive_f, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost, ctx->stream));

@@ -550,7 +550,10 @@ def main():
                        "kernel": name, "launches_per_frame": round(len(late) / fpc, 3), "avg_launch_ms": round(t_late / len(late), 5),
                        "ms_per_frame": round(t_late / fpc, 4), "frames_per_launch": fpc, "launches_timed": nsel * len(late),
                        "trace_calls_of_the_timed_region": [int(v) for v in fr_calls],
-                       "timing_note": "HIP-event pairs around every bounce launch of a second, untimed pass over the timed region's frames",
+                       "timing_note": "HIP-event pairs around every bounce launch of a second, untimed pass over the timed region's frames; "
+                                      "while they record, a call's frames are traced by ONE set of launches (the kernel alone, as the PMC "
+                                      "passes see it); in the timed region aipt_frames traces the two halves of a call side by side on two "
+                                      "streams (half the frames per launch each: their launch floors hide behind each other)",
                        "algorithmic_bytes_per_launch": by_late / len(late),
                        "byte_model": "SURVEY 8d: sum over bounces of N_b x 160 B (44 B state read + 44 B write, 36 B hit record "
                                      "write + read of the reference's layout); BVH and triangle fetches are overhead, not algorithmic",
@@ -592,9 +595,9 @@ def main():
                                    f"BN {args.bn}-stats, hidden {args.hidden}, conv {args.impl}",
                        "frames_per_gpu": args.steps, "denoiser_input": f"10x{Hp}x{Wp}",
                        "weights": "synthetic Kaiming-variance uniform, seed 565", "parallelism": f"frame-shard x{world}",
-                       "pipelining": ((f"throughput mode: a call holds up to {B} consecutive frames; their traces share launches (at most "
-                                       f"24 frames per launch set) and their denoiser passes run on two streams, frame n+1 one encoder "
-                                       f"level behind frame n (aipt_frames)" if B > 1 else
+                       "pipelining": ((f"throughput mode: a call holds up to {B} consecutive frames; their traces share launches (the two halves "
+                                       f"of a call side by side on two streams, at most 24 frames per pair of launch sets) and their denoiser "
+                                       f"passes run on two streams, frame n+1 one encoder level behind frame n (aipt_frames)" if B > 1 else
                                       "frame by frame" + ("; the next frame's trace runs beside this frame's denoise on disjoint CUs" if args.prefetch else ""))
                                       + "; frames bit-identical to un-pipelined rendering")},
             # the mode `value` is quoted in: a batch of frames is in flight together, so the first frame of a call is delivered

@@ -32,6 +32,8 @@
  *   AIPT_TRACE_POOL=0 / 1       batched traces: never / always pool the BVH walks of a workgroup's paths (default: from 4 frames
  *                               per launch on)
  *   AIPT_PREFETCH_TRACE_CUS=n   aipt_frame_prefetch: CUs of the trace stream's mask (default: half of the chip)
+ *   AIPT_TRACE_LANES=1          aipt_frames: trace a call's frames with ONE set of launches instead of two half-batches side by
+ *                               side on two streams (default 2)
  * Everything else (kernel selection, tile sizes) is an explicit ABI option (aipt_denoise_set_option) or a debug-build hook
  * behind -DAIPT_DEBUG_HOOKS; tests/test_shipped_kernels_cpu.py fails on any other getenv in the kernels' sources.
  */
@@ -190,7 +192,7 @@ int aipt_trace(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
 int aipt_trace_configure_batch(aipt_ctx* ctx, int width, int height, int batch);
 int aipt_trace_batch(aipt_ctx* ctx, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t flags,
                      float* d_gbuf, int gbuf_rows, int gbuf_stride, size_t gbuf_frame_floats);
-int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n);   /* of one frame of the last batch */
+int aipt_trace_live_counts_frame(aipt_ctx* ctx, int frame, int* h_n_live, int n);   /* of one frame of the last batch (aipt_frames: of its last trace call, both lanes) */
 /* HIP-event timing of the bounce launches on the stream they are launched on (bench.py's roofline leg): up to max_calls
  * traces are recorded, every `every`-th one after _begin; _end synchronises and returns the summed ms of bounce b's launch in
  * sum_ms_per_bounce[b] (b < nbounces) and the number of recorded traces.  aipt_trace_kernel_name: the kernel instantiation

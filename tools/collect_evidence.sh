@@ -8,10 +8,10 @@ export TMPDIR=/tmp
 O=gpurun_out/ev
 rm -rf $O; mkdir -p $O
 B="python bench.py"
-# PMC: the bench command with one denoiser stream, so that a counter belongs to one kernel (two kernels in flight share the
+# PMC: the bench command with one denoiser stream and one trace lane, so that a counter belongs to one kernel (two kernels in flight share the
 # chip-wide counters); a bounce launch covers 16 frames either way
 P="$B --steps 20 --warmup 20 --no-cpu-baseline --no-roofline-events"   # (every batched trace launch holds 20 frames, as in the driver's command)
-pass() { tag=$1; shift; AIPT_DN_PIPELINE=0 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- $P > $O/pmc_$tag.log 2>&1; echo "pass $tag rc=$?"; }
+pass() { tag=$1; shift; AIPT_DN_PIPELINE=0 AIPT_TRACE_LANES=1 timeout 300 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $O/pmc_$tag -o p -- $P > $O/pmc_$tag.log 2>&1; echo "pass $tag rc=$?"; }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU
@@ -32,12 +32,13 @@ $B --batch 1 --no-cpu-baseline > $O/bench_frame_by_frame.json 2>/dev/null
 $B --batch 1 --prefetch --no-cpu-baseline > $O/bench_frame_by_frame_prefetch.json 2>/dev/null
 AIPT_DN_PIPELINE=0 $B --no-cpu-baseline > $O/bench_one_denoiser_stream.json 2>/dev/null
 AIPT_TRACE_POOL=0 $B --no-cpu-baseline > $O/bench_fused_walk.json 2>/dev/null
+AIPT_TRACE_LANES=1 $B --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_one_trace_lane.json 2>/dev/null
 for c in 0 1 3 4; do $B --config $c --no-cpu-baseline > $O/bench_config$c.json 2>/dev/null; done
 $B --no-cpu-baseline --bn running --hidden reset > $O/bench_running_reset.json 2>/dev/null
 $B --no-cpu-baseline --impl f32 --steps 32 > $O/bench_f32exact.json 2>/dev/null
 $B --no-cpu-baseline --trace-flags 35 --batch 1 --steps 30 > $O/bench_sort_material.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats -o k -- $B --no-cpu-baseline > $O/kstats.log 2>&1
-AIPT_DN_PIPELINE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_one_stream -o k -- $B --no-cpu-baseline > $O/kstats_one_stream.log 2>&1
+AIPT_DN_PIPELINE=0 AIPT_TRACE_LANES=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kstats_one_stream -o k -- $B --no-cpu-baseline > $O/kstats_one_stream.log 2>&1
 # round 4: the driver's own command first (what BENCH_rNN.json reproduces), 300-frame pans of configs[1] / [2] (BASELINE.json),
 # the drift study ON the register-staged kernel, the two-stream timeline with the call queued behind a spin
 $B --steps 20 --warmup 5 > $O/bench_driver_command.json 2>/dev/null

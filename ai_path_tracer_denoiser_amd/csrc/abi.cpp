@@ -305,10 +305,11 @@ static int trace_frames(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cams, 
     // pooled walks of a 4-frame call refill their lanes from a quarter of the rays)
     const int ncalls = (nframes + AIPT_TRACE_BATCH_MAX - 1) / AIPT_TRACE_BATCH_MAX;
     // [r5] Two lanes: from AIPT_TRACE_LANES_MIN (2) frames on, the two halves of a call's frames are traced BESIDE each other -- the
-    // first on `st`, the second on a side stream with its own path state.  A bounce launch lasts at least as long as its longest
-    // ray's chain of dependent node visits (~0.15 ms whatever the ray count: seven such floors per trace), and two launch
-    // sequences side by side fill each other's tails: 0.333 vs 0.382 ms per frame at 20 frames, 0.326 vs 0.387 at 24
-    // (tools/dual_trace_probe.py); calls of 2 / 4 / 8 frames: 718 / 813 / 887 against 668 / 756 / 804 frames/s.  Frames are independent, so the split changes no bit (tests/test_gpu_frame.py).
+    // first on `st`, the second on a side stream with its own path state.  Every bounce launch ends in a tail (its last workgroups
+    // walk their longest rays while the rest of the chip has run out of work: a single frame's later bounces last 105-150 us
+    // whatever their ray count), seven in a row per trace; two launch sequences side by side fill each other's tails: 0.333 vs
+    // 0.382 ms per frame at 20 frames, 0.326 vs 0.387 at 24 (tools/dual_trace_probe.py); calls of 2 / 4 / 8 frames: 718 / 813 / 887
+    // against 668 / 756 / 804 frames/s.  Frames are independent, so the split changes no bit (tests/test_gpu_frame.py).
     // AIPT_TRACE_LANES=1 keeps one lane (scheduling only; profiling passes that want one kernel at a time).
     static const int lanes_env = getenv("AIPT_TRACE_LANES") ? atoi(getenv("AIPT_TRACE_LANES")) : 2;
     for (int c = 0, k = 0; c < ncalls; c++) {

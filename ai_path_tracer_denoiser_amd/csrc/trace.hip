@@ -88,8 +88,8 @@ struct TraceState {
     std::vector<int> prof_frames;                 // [call] frames the recorded call held
     char kname[2][40] = {};                       // instantiation that ran bounce 0 / the later bounces in the last trace
     // Second LANE of per-path buffers (lane 1 of trace_on_stream): aipt_frames traces the two halves of a call's frames BESIDE
-    // each other on two streams (a bounce launch lasts at least as long as its longest ray's chain of dependent node visits,
-    // ~0.15 ms whatever the ray count; two launch sequences side by side hide each other's floors).  The lane shares the scene
+    // each other on two streams (every bounce launch ends in a tail -- its longest rays' chains of dependent node visits -- and
+    // two launch sequences side by side fill each other's tails).  The lane shares the scene
     // (pointers copied at every trace) and owns only its path state, sized for half of the batch.
     TraceState* side = nullptr;
     bool is_side = false;

@@ -61,7 +61,7 @@ def test_packed_bvh_is_valid(make):
             if ref < 0:
                 v = -ref - 1
                 first, cnt = v >> 3, v & 7
-                assert 1 <= cnt <= 4 and not seen[first:first + cnt].any()
+                assert 1 <= cnt <= 7 and not seen[first:first + cnt].any()      # BVH_LEAF_FACES (csrc/internal.h)
                 seen[first:first + cnt] = True
                 lo, hi = tlo[first:first + cnt].min(axis=0), thi[first:first + cnt].max(axis=0)
             else:

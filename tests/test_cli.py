@@ -67,9 +67,9 @@ def _mesh_scene_file(tmp_path, ntri=2048):
     return str(p)
 
 
-def _run_cli(scene, out, *extra):
+def _run_cli(scene, out, *extra, env=None):
     r = subprocess.run([CLI, scene, "--res", "96", "64", "--depth", "4", "--out", str(out), "--npy"] + list(extra),
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stderr + r.stdout
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -106,6 +106,14 @@ def test_cli_batched_frames_and_gpu_count_check(tmp_path):
     assert b3["batch"] == 3
     for (g1, d1), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / "b3", 7)):
         assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))
+    # [r5] a batch's traces run as two half-batches side by side on two streams (lanes); AIPT_TRACE_LANES=1 keeps one set of
+    # launches: scheduling only, the same bytes (batches of 6 and 7 frames: 3 + 3 and 4 + 3 per lane)
+    for nb in ("6", "7"):
+        _run_cli(scene, tmp_path / f"two{nb}", "--frames", "7", "--hidden", "carry", "--batch", nb)
+        _run_cli(scene, tmp_path / f"one{nb}", "--frames", "7", "--hidden", "carry", "--batch", nb, env={"AIPT_TRACE_LANES": "1"})
+        for (g1, d1), (g2, d2), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / f"two{nb}", 7), _frames(tmp_path / f"one{nb}", 7)):
+            assert np.array_equal(g1.view(np.uint32), g2.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d2.view(np.uint32))
+            assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))
     pf = _run_cli(scene, tmp_path / "pf", "--frames", "7", "--hidden", "carry", "--prefetch")     # trace k+1 beside denoise k
     for (g1, d1), (g3, d3) in zip(_frames(tmp_path / "b1", 7), _frames(tmp_path / "pf", 7)):
         assert np.array_equal(g1.view(np.uint32), g3.view(np.uint32)) and np.array_equal(d1.view(np.uint32), d3.view(np.uint32))

@@ -57,6 +57,7 @@ struct TraceState {
     Bvh4Node* d_nodes = nullptr; int nnodes = 0;     // 4-wide BVH over the faces (bvh.cpp)
     TriRec* d_tris = nullptr;                        // leaf-ordered triangle records
     DevFaceP* d_lfaces = nullptr;                    // leaf-ordered full faces
+    int* d_fslot = nullptr;                          // face index (caller's order) -> leaf slot
     aipt_aabb box{};
     bool have_scene = false;
     int W = 0, H = 0, P = 0, nblk = 0;
@@ -114,6 +115,7 @@ struct TraceParams {
     const Bvh4Node* nodes;
     const TriRec* tris;
     const DevFaceP* lfaces;
+    const int* fslot;            // leaf slot of a face index (the split walk's results are (distance, face index) keys)
     aipt_aabb box;
     float* gbuf; size_t plane; int stride;
     int* cnt;                    // per-workgroup live counts (bounce -> compact)
@@ -525,13 +527,17 @@ __device__ __forceinline__ float triHitT_flat(v3 v0, v3 e1, v3 e2, v3 orig, v3 d
 constexpr int STACK_LDS = 8;
 struct WalkStack {
     int* lds; int* ovf; size_t ostride; int sp;
+    int bot;                        // entries [bot, sp) are live: the split walk gives its bottom entries away (steal_step)
     __device__ __forceinline__ void push(int v) {
         if (sp < STACK_LDS) lds[sp * 256] = v; else ovf[(size_t)(sp - STACK_LDS) * ostride] = v;
         sp++;
     }
+    __device__ __forceinline__ bool empty() const { return sp == bot; }
     __device__ __forceinline__ int pop() {
         sp--;
-        return sp < STACK_LDS ? lds[sp * 256] : ovf[(size_t)(sp - STACK_LDS) * ostride];
+        const int v = sp < STACK_LDS ? lds[sp * 256] : ovf[(size_t)(sp - STACK_LDS) * ostride];
+        if (sp == bot) { sp = 0; bot = 0; }
+        return v;
     }
 };
 
@@ -602,7 +608,7 @@ __device__ __forceinline__ void walk_node(const uint4* nodes, const WalkRay& r, 
     if (st.sp > 12) STAT_ADD(15, 1);
 #endif
     if (key[0] < INFINITY) cur = ref[0];
-    else cur = st.sp ? st.pop() : WALK_DONE;
+    else cur = st.empty() ? WALK_DONE : st.pop();
 }
 
 // one leaf: the reference's triangle test on its (<= 7) triangles, two per memory round trip
@@ -713,19 +719,84 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
             r.best_slot = cl.slot[lane];
         }
         STAT_ADD(4, 1);
-        cur = st.sp ? st.pop() : WALK_DONE;
+        cur = st.empty() ? WALK_DONE : st.pop();
     }
     STAT_WAVE(3);
 }
 
+// ---- split walks [r5].  A wave that walks 64 rays to the end runs the UNION of their walks -- 47 node trips for 7 node visits per
+// ray on the atrium -- because a few rays take 30-70 visits while the lanes of the others idle.  Here an idle lane takes over part
+// of a busy lane's walk: the BOTTOM entry of its traversal stack (a whole subtree, the farthest child pushed at the shallowest
+// node) together with a copy of its ray.  All pieces of a ray's walk report to one 64-bit LDS word of the ray's owner lane,
+// (bits of t, face index), by atomicMin: the reference's "first strictly smaller t wins, ties to the lowest face index" as an
+// order-independent minimum (the word starts as (bound, 0): a face AT the bound -- a primitive's distance -- is never below it),
+// and every piece prunes with the word's distance, which only falls.  Which lane walks which subtree therefore changes how many
+// boxes are visited, never the result: bit-exact with the unsplit walk (and the brute-force loop).
+constexpr int STEAL_MIN_IDLE = 8;                              // idle lanes of a wave that make a round of takeovers worth its ~60 instructions
+__device__ __forceinline__ unsigned long long walk_key(const WalkRay& r) {
+    return ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
+}
+struct SplitWalk {
+    unsigned long long* wbest;     // [64] of this wave: the nearest face found so far for the ray that started in lane k
+    int owner;                     // the lane whose ray this lane is walking (a part of)
+    bool shared;                   // that ray is being walked by more than one lane: prune with wbest[owner], report to it
+    bool dirty;                    // this lane has a (part of a) walk whose result is not yet in wbest[owner]
+};
+__device__ __forceinline__ void steal_step(WalkRay& r, WalkStack& st, int& cur, SplitWalk& sw, const CoopLeaf& cl, int lane) {
+    // a finished part reports before its lane is counted idle
+    if (cur == WALK_DONE && sw.dirty) {
+        if (r.best_face >= 0) atomicMin(&sw.wbest[sw.owner], walk_key(r));
+        sw.dirty = false;
+    }
+    const unsigned long long idle = __ballot(cur == WALK_DONE);
+    if (__popcll(idle) < STEAL_MIN_IDLE) return;
+    const bool can_give = cur != WALK_DONE && !st.empty() && st.bot < STACK_LDS;       // (its bottom entry is in LDS)
+    const unsigned long long don = __ballot(can_give);
+    if (!don) return;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n = min(__popcll(idle), __popcll(don));
+    const int rd = __popcll(don & below), ri = __popcll(idle & below);
+    if (can_give && rd < n) {
+        // (the owner reports what it has so far, so that the taker starts with the ray's current bound)
+        if (r.best_face >= 0) atomicMin(&sw.wbest[sw.owner], walk_key(r));
+        cl.pairs[rd] = (unsigned)lane | ((unsigned)st.bot << 8) | ((unsigned)sw.owner << 16);
+        cl.rays[3 * lane] = make_float2(r.o.x, r.o.y);
+        cl.rays[3 * lane + 1] = make_float2(r.o.z, r.d.x);
+        cl.rays[3 * lane + 2] = make_float2(r.d.y, r.d.z);
+        st.bot++;
+        if (st.sp == st.bot) { st.sp = 0; st.bot = 0; }        // (the entry itself stays where it is until the taker has read it, below)
+        sw.shared = true;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (cur == WALK_DONE && ri < n) {
+        const unsigned pr = cl.pairs[ri];
+        const int dl = (int)(pr & 0xffu), b = (int)((pr >> 8) & 0xffu);
+        sw.owner = (int)(pr >> 16);
+        cur = st.lds[b * 256 + (dl - lane)];                   // the giver's stack column, entry b
+        const float2 ra = cl.rays[3 * dl], rb = cl.rays[3 * dl + 1], rc = cl.rays[3 * dl + 2];
+        const unsigned long long bound = sw.wbest[sw.owner];
+        r.start(V(ra.x, ra.y, rb.x), V(rb.y, rc.x, rc.y), __uint_as_float((unsigned)(bound >> 32)));
+        // the whole word, face index included: a face at the SAME distance as the ray's nearest so far wins with a lower index only
+        // (index 0 of the untouched word "(bound, 0)": nothing at the bound's distance wins, as it must not)
+        r.best_face = (int)(unsigned)bound;
+        st.sp = 0; st.bot = 0;
+        sw.shared = true; sw.dirty = true;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot,
-                                             const CoopLeaf& cl, int lane, bool walk) {
+                                             const CoopLeaf& cl, unsigned long long* wbest, int lane, bool walk) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
     const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
     WalkRay r;
     r.start(o, d, t_min);
     int cur = walk ? 0 : WALK_DONE;                            // (lanes whose ray misses the mesh box help with the leaf steps)
-    st.sp = 0;
+    st.sp = 0; st.bot = 0;
 #ifdef AIPT_TRACE_STATS
     int my_visits = 0;
 #define STAT_MINE() my_visits++
@@ -733,17 +804,44 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
 #define STAT_MINE() do {} while (0)
 #endif
     if (AIPT_POOL_COOP_LEAF) {
-        // wave-level "while-while": every lane descends to its next leaf, then ALL 64 lanes share the leaves' triangle tests
+        // wave-level "while-while": every lane descends to its next leaf, then ALL 64 lanes share the leaves' triangle tests;
+        // idle lanes take over parts of the busy lanes' walks (steal_step)
+        const unsigned long long key0 = walk_key(r);
+        SplitWalk sw{wbest, lane, false, walk};
+        wbest[lane] = key0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         while (true) {
-            while (__ballot(cur >= 0)) {
+            while (true) {
+                steal_step(r, st, cur, sw, cl, lane);
+                if (!__ballot(cur >= 0)) break;
                 if (cur >= 0) {
+                    if (sw.shared) {                           // the other parts of this ray's walk may have found something nearer
+                        const unsigned long long wb = sw.wbest[sw.owner];
+                        const float tb = __uint_as_float((unsigned)(wb >> 32));
+                        if (tb < r.t_min) { r.t_min = tb; r.best_face = (int)(unsigned)wb; }   // (a real face: the word only falls through faces)
+                    }
                     STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
                     walk_node(nodes, r, st, cur);
                 }
             }
             if (!__ballot(cur != WALK_DONE)) break;
+            const float t_before = r.t_min;
             coop_leaf_step(tris, r, st, cur, cl, lane);
+            if (sw.shared && r.t_min < t_before) atomicMin(&sw.wbest[sw.owner], walk_key(r));
         }
+        // (every part has reported: a lane only turns idle through steal_step's first lines, and the loop ends with all lanes idle)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long res = wbest[lane];
+        best_slot = -1;
+        if (walk && res != key0) {                             // a face strictly below the bound (or, between faces, the lowest index)
+            t_min = __uint_as_float((unsigned)(res >> 32));
+            best_slot = p.fslot[(unsigned)res];
+        }
+        return;
     } else {
     while (true) {
         while (cur >= 0) {
@@ -752,7 +850,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
         }
         if (cur == WALK_DONE) break;
         walk_leaf(tris, r, cur);
-        cur = st.sp ? st.pop() : WALK_DONE;
+        cur = st.empty() ? WALK_DONE : st.pop();
         if (cur == WALK_DONE) break;
     }
     }
@@ -828,7 +926,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
     r.start(V(0, 0, 0), V(1, 1, 1), FLT_MAX);
     int cur = WALK_DONE, lid = -1;
     bool exhausted = pool_n == 0;
-    st.sp = 0;
+    st.sp = 0; st.bot = 0;
     while (true) {
         if (cur == WALK_DONE && lid >= 0) {                         // finished since the last look: hand the result over
             s_res[lid] = r.best_slot;                               // (the distance comes back with the winner's full test)
@@ -848,7 +946,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
                     const float4 a = S0[i], b = S1[i];
                     r.start(V(a.x, a.y, a.z), V(a.w, b.x, b.y), FLT_MAX);
                     cur = 0;
-                    st.sp = 0;
+                    st.sp = 0; st.bot = 0;
                 }
             }
             exhausted = base + nidle >= pool_n;
@@ -879,7 +977,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
             if (AIPT_POOL_COOP_LEAF) coop_leaf_step(tris, r, st, cur, cl, lane);
             else if (cur < 0 && cur != WALK_DONE) {
                 walk_leaf(tris, r, cur);
-                cur = st.sp ? st.pop() : WALK_DONE;
+                cur = st.empty() ? WALK_DONE : st.pop();
             }
         } else if (cur >= 0) {
             STAT_ADD(0, 1); STAT_WAVE(1);
@@ -962,6 +1060,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     __shared__ unsigned long long s_best[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
     __shared__ int s_slot[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
     __shared__ float2 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 768 : 1];
+    __shared__ unsigned long long s_wbest[MESH && !POOL && AIPT_POOL_COOP_LEAF ? 256 : 1];   // split walks of the un-pooled kernel: per wave, per owner lane
     const CoopLeaf cl{s_pairs + (MESH && AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
                       s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 192 : 0)};
     if (POOL) {
@@ -983,7 +1082,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
             if (walker) s_pool[base + __popcll(m & ((1ull << lane) - 1ull))] = j * 256 + tid;
         }
         __syncthreads();
-        WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0};
+        WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0, 0};
         pool_walk(p, s_pool, s_pool_n, &s_head, s_res, st, lane, cl);
         __syncthreads();
         PHASE(2);
@@ -1116,8 +1215,8 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     }
     if (MESH && !POOL && __syncthreads_or(want_walk)) {           // (workgroup-uniform: the cooperative leaf step's LDS slices are per wave)
         int best_slot = -1;
-        WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0};
-        bvh4_nearest(p, o, d, st, t_min, best_slot, cl, lane, want_walk);
+        WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0, 0};
+        bvh4_nearest(p, o, d, st, t_min, best_slot, cl, s_wbest + (MESH && !POOL && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), lane, want_walk);
         if (best_slot >= 0) {
             // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
             DevFace f;
@@ -1374,9 +1473,9 @@ __global__ __launch_bounds__(256) void trace_sort_scatter(const TraceParams p) {
 }
 
 static void free_scene(TraceState* s) {
-    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_lfaces);
+    hipFree(s->d_geoms); hipFree(s->d_mats); hipFree(s->d_faces); hipFree(s->d_nodes); hipFree(s->d_tris); hipFree(s->d_lfaces); hipFree(s->d_fslot);
     s->d_geoms = nullptr; s->d_mats = nullptr; s->d_faces = nullptr; s->have_scene = false;
-    s->d_nodes = nullptr; s->d_tris = nullptr; s->d_lfaces = nullptr; s->nnodes = 0; s->cache_valid = false;
+    s->d_nodes = nullptr; s->d_tris = nullptr; s->d_lfaces = nullptr; s->d_fslot = nullptr; s->nnodes = 0; s->cache_valid = false;
 }
 static void free_frame(TraceState* s) {
     hipFree(s->d_state); hipFree(s->d_cnt); hipFree(s->d_alive); hipFree(s->d_nlive); hipFree(s->d_mat0); hipFree(s->d_image);
@@ -1585,6 +1684,12 @@ int aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes) {
         AIPT_HIP(ctx, hipMemcpy(s->d_nodes, v.nodes, sizeof(Bvh4Node) * nnodes, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(s->d_tris, v.tris, sizeof(TriRec) * nfaces, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(s->d_lfaces, lf.data(), sizeof(DevFaceP) * nfaces, hipMemcpyHostToDevice));
+        std::vector<int> fslot(nfaces, -1);
+        for (int k = 0; k < nfaces; k++) fslot[v.tris[k].face] = k;
+        for (int k = 0; k < nfaces; k++)
+            if (fslot[k] < 0) return fail(ctx, AIPT_E_FORMAT, "packed scene: face %d is in no leaf", k);
+        AIPT_HIP(ctx, hipMalloc((void**)&s->d_fslot, sizeof(int) * nfaces));
+        AIPT_HIP(ctx, hipMemcpy(s->d_fslot, fslot.data(), sizeof(int) * nfaces, hipMemcpyHostToDevice));
         s->nnodes = nnodes;
     } else {
         memset(&s->box, 0, sizeof(s->box));
@@ -1707,7 +1812,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         if (!d || !d->d_state || d->W != m->W || d->H != m->H) return fail(ctx, AIPT_E_STATE, "aipt_trace: the side lane is not configured");
         d->d_geoms = m->d_geoms; d->ngeoms = m->ngeoms; d->d_mats = m->d_mats; d->nmats = m->nmats;
         d->d_faces = m->d_faces; d->nfaces = m->nfaces; d->stack_need = m->stack_need;
-        d->d_nodes = m->d_nodes; d->nnodes = m->nnodes; d->d_tris = m->d_tris; d->d_lfaces = m->d_lfaces;
+        d->d_nodes = m->d_nodes; d->nnodes = m->nnodes; d->d_tris = m->d_tris; d->d_lfaces = m->d_lfaces; d->d_fslot = m->d_fslot;
         d->box = m->box; d->have_scene = true;
         s = d;
     }
@@ -1785,7 +1890,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     p.st = s->d_state;
     p.geoms = s->d_geoms; p.ngeoms = s->ngeoms; p.mats = s->d_mats; p.nmats = s->nmats;
     p.faces = s->d_faces; p.nfaces = s->nfaces; p.box = s->box;
-    p.nodes = s->d_nodes; p.tris = s->d_tris; p.lfaces = s->d_lfaces;
+    p.nodes = s->d_nodes; p.tris = s->d_tris; p.lfaces = s->d_lfaces; p.fslot = s->d_fslot;
     p.gbuf = d_gbuf; p.plane = (size_t)gbuf_rows * gbuf_stride; p.stride = gbuf_stride;
     p.cnt = s->d_cnt; p.alive = s->d_alive;
     p.n_live = s->d_nlive;

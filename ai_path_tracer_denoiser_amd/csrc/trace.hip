@@ -665,7 +665,11 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
     return x;
 }
-__device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, WalkStack& st, int& cur, const CoopLeaf& cl, int lane) {
+// SPLIT (split walks, below): the result word of a ray is cl.best[the ray's OWNER lane] for as long as the wave walks -- the lanes
+// at a leaf name their ray's owner in cl.slot and every tester reports straight to the owner's word -- instead of a per-step word
+// of the lane that holds the leaf.
+template <bool SPLIT>
+__device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, WalkStack& st, int& cur, const CoopLeaf& cl, int lane, int ray_owner) {
     const bool at_leaf = cur < 0 && cur != WALK_DONE;
     const int v = -cur - 1, first = v >> 3, cnt = at_leaf ? (v & 7) : 0;
     const int incl = wave_incl_scan(cnt);                      // inclusive prefix of the triangle counts over the wave
@@ -674,7 +678,7 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
     // it (strict t_min > t in the reference's loop): its key (t, f >= 0) is never below (t, 0))
     const unsigned long long mine = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
     if (at_leaf) {
-        cl.best[lane] = mine;
+        if (SPLIT) cl.slot[lane] = ray_owner; else cl.best[lane] = mine;
         cl.rays[3 * lane] = make_float2(r.o.x, r.o.y);                        // the owners' rays: three 8-byte reads per tester
         cl.rays[3 * lane + 1] = make_float2(r.o.z, r.d.x);
         cl.rays[3 * lane + 2] = make_float2(r.d.y, r.d.z);
@@ -687,9 +691,10 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
         const int pi = base + lane;
         const bool work = pi < total;
         const unsigned pr = cl.pairs[work ? pi : 0];
-        const int owner = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
-        const float2 ra = cl.rays[3 * owner], rb = cl.rays[3 * owner + 1], rc = cl.rays[3 * owner + 2];
+        const int holder = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
+        const float2 ra = cl.rays[3 * holder], rb = cl.rays[3 * holder + 1], rc = cl.rays[3 * holder + 2];
         const v3 o = V(ra.x, ra.y, rb.x), d = V(rb.y, rc.x, rc.y);
+        const int target = SPLIT ? cl.slot[holder] : holder;
         unsigned long long key = ~0ull;
         if (work) {
             const uint4* tr = tris + (unsigned)slot * 3u;
@@ -699,24 +704,32 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
                                           V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), o, d);
             if (ta > 0.0f) {
                 key = ((unsigned long long)__float_as_uint(ta) << 32) | (unsigned)r2.y;
-                atomicMin(&cl.best[owner], key);
+                atomicMin(&cl.best[target], key);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (key != ~0ull && cl.best[owner] == key) cl.slot[owner] = slot;      // the (so far) nearest face of that ray: its leaf slot
+        if (!SPLIT) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (key != ~0ull && cl.best[holder] == key) cl.slot[holder] = slot;      // the (so far) nearest face of that ray: its leaf slot
+        }
         STAT_ADD(2, work ? 1 : 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (at_leaf) {
-        const unsigned long long b = cl.best[lane];
-        if (b != mine) {                                       // a face of this leaf is nearer (or as near with a lower index)
+        if (SPLIT) {                                           // the ray's word, whoever lowered it
+            const unsigned long long b = cl.best[ray_owner];
             r.t_min = __uint_as_float((unsigned)(b >> 32));
             r.best_face = (int)(unsigned)b;
-            r.best_slot = cl.slot[lane];
+        } else {
+            const unsigned long long b = cl.best[lane];
+            if (b != mine) {                                   // a face of this leaf is nearer (or as near with a lower index)
+                r.t_min = __uint_as_float((unsigned)(b >> 32));
+                r.best_face = (int)(unsigned)b;
+                r.best_slot = cl.slot[lane];
+            }
         }
         STAT_ADD(4, 1);
         cur = st.empty() ? WALK_DONE : st.pop();
@@ -726,63 +739,67 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
 
 // ---- split walks [r5].  A wave that walks 64 rays to the end runs the UNION of their walks -- 47 node trips for 7 node visits per
 // ray on the atrium -- because a few rays take 30-70 visits while the lanes of the others idle.  Here an idle lane takes over part
-// of a busy lane's walk: the BOTTOM entry of its traversal stack (a whole subtree, the farthest child pushed at the shallowest
-// node) together with a copy of its ray.  All pieces of a ray's walk report to one 64-bit LDS word of the ray's owner lane,
-// (bits of t, face index), by atomicMin: the reference's "first strictly smaller t wins, ties to the lowest face index" as an
-// order-independent minimum (the word starts as (bound, 0): a face AT the bound -- a primitive's distance -- is never below it),
-// and every piece prunes with the word's distance, which only falls.  Which lane walks which subtree therefore changes how many
-// boxes are visited, never the result: bit-exact with the unsplit walk (and the brute-force loop).
-constexpr int STEAL_MIN_IDLE = 8;                              // idle lanes of a wave that make a round of takeovers worth its ~60 instructions
-__device__ __forceinline__ unsigned long long walk_key(const WalkRay& r) {
-    return ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
-}
+// of a busy lane's walk: the BOTTOM entry of its traversal stack (a whole subtree: the farthest child pushed at the shallowest
+// node) together with a copy of its ray.  All parts of a ray's walk share one 64-bit LDS word, that of the ray's OWNER lane
+// (cl.best[owner]): (bits of t, face index), lowered by atomicMin -- the reference's "first strictly smaller t wins, ties to the
+// lowest face index" as an order-independent minimum (the word starts as (bound, 0): a face AT the bound -- a primitive's
+// distance -- is never below it) -- and every part prunes with the word's distance, which only falls.  Which lane walks which
+// subtree therefore changes how many boxes are visited, never the result: bit-exact with the unsplit walk and the brute-force
+// loop.  The winner's leaf slot comes from its face index (TraceParams::fslot).
+constexpr int STEAL_MIN_IDLE = 8;                              // idle lanes that make a round of takeovers worth its ~60 instructions (4 .. 16: +-0.5 %)
 struct SplitWalk {
-    unsigned long long* wbest;     // [64] of this wave: the nearest face found so far for the ray that started in lane k
     int owner;                     // the lane whose ray this lane is walking (a part of)
-    bool shared;                   // that ray is being walked by more than one lane: prune with wbest[owner], report to it
-    bool dirty;                    // this lane has a (part of a) walk whose result is not yet in wbest[owner]
+    bool shared;                   // that ray is walked by more than one lane: refresh the pruning distance from its word
 };
-__device__ __forceinline__ void steal_step(WalkRay& r, WalkStack& st, int& cur, SplitWalk& sw, const CoopLeaf& cl, int lane) {
-    // a finished part reports before its lane is counted idle
-    if (cur == WALK_DONE && sw.dirty) {
-        if (r.best_face >= 0) atomicMin(&sw.wbest[sw.owner], walk_key(r));
-        sw.dirty = false;
+__device__ __forceinline__ void split_refresh(WalkRay& r, const SplitWalk& sw, const CoopLeaf& cl) {
+    if (sw.shared) {                                           // the other parts of this ray's walk may have found something nearer
+        const unsigned long long wb = cl.best[sw.owner];
+        const float tb = __uint_as_float((unsigned)(wb >> 32));
+        if (tb < r.t_min) { r.t_min = tb; r.best_face = (int)(unsigned)wb; }   // (a real face: the word only falls through faces)
     }
+}
+#ifndef AIPT_STEAL_GIVE
+#define AIPT_STEAL_GIVE 4
+#endif
+constexpr int STEAL_GIVE = AIPT_STEAL_GIVE;                    // most entries one lane gives away per round (to as many takers)
+__device__ __forceinline__ void steal_step(WalkRay& r, WalkStack& st, int& cur, SplitWalk& sw, const CoopLeaf& cl, int lane) {
     const unsigned long long idle = __ballot(cur == WALK_DONE);
-    if (__popcll(idle) < STEAL_MIN_IDLE) return;
-    const bool can_give = cur != WALK_DONE && !st.empty() && st.bot < STACK_LDS;       // (its bottom entry is in LDS)
-    const unsigned long long don = __ballot(can_give);
-    if (!don) return;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const int n = min(__popcll(idle), __popcll(don));
-    const int rd = __popcll(don & below), ri = __popcll(idle & below);
-    if (can_give && rd < n) {
-        // (the owner reports what it has so far, so that the taker starts with the ray's current bound)
-        if (r.best_face >= 0) atomicMin(&sw.wbest[sw.owner], walk_key(r));
-        cl.pairs[rd] = (unsigned)lane | ((unsigned)st.bot << 8) | ((unsigned)sw.owner << 16);
+    const int nidle = __popcll(idle);
+    if (nidle < STEAL_MIN_IDLE) return;
+    // entries [bot, bot + g) of a busy lane's stack, while they are in LDS
+    int g = 0;
+    if (cur != WALK_DONE) g = min(min(st.sp, STACK_LDS) - st.bot, STEAL_GIVE);
+    g = max(g, 0);
+    if (!__ballot(g > 0)) return;
+    const int incl = wave_incl_scan(g), excl = incl - g;
+    const int n = min(nidle, __builtin_amdgcn_readlane(incl, 63));
+    const int taken = min(max(n - excl, 0), g);
+    if (taken > 0) {
+        for (int k = 0; k < taken; k++) cl.pairs[excl + k] = (unsigned)lane | ((unsigned)(st.bot + k) << 8) | ((unsigned)sw.owner << 16);
         cl.rays[3 * lane] = make_float2(r.o.x, r.o.y);
         cl.rays[3 * lane + 1] = make_float2(r.o.z, r.d.x);
         cl.rays[3 * lane + 2] = make_float2(r.d.y, r.d.z);
-        st.bot++;
-        if (st.sp == st.bot) { st.sp = 0; st.bot = 0; }        // (the entry itself stays where it is until the taker has read it, below)
+        st.bot += taken;
+        if (st.sp == st.bot) { st.sp = 0; st.bot = 0; }        // (the entries themselves stay where they are until the takers have read them, below)
         sw.shared = true;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int ri = __popcll(idle & ((1ull << lane) - 1ull));
     if (cur == WALK_DONE && ri < n) {
         const unsigned pr = cl.pairs[ri];
         const int dl = (int)(pr & 0xffu), b = (int)((pr >> 8) & 0xffu);
         sw.owner = (int)(pr >> 16);
         cur = st.lds[b * 256 + (dl - lane)];                   // the giver's stack column, entry b
         const float2 ra = cl.rays[3 * dl], rb = cl.rays[3 * dl + 1], rc = cl.rays[3 * dl + 2];
-        const unsigned long long bound = sw.wbest[sw.owner];
+        const unsigned long long bound = cl.best[sw.owner];
         r.start(V(ra.x, ra.y, rb.x), V(rb.y, rc.x, rc.y), __uint_as_float((unsigned)(bound >> 32)));
         // the whole word, face index included: a face at the SAME distance as the ray's nearest so far wins with a lower index only
         // (index 0 of the untouched word "(bound, 0)": nothing at the bound's distance wins, as it must not)
         r.best_face = (int)(unsigned)bound;
         st.sp = 0; st.bot = 0;
-        sw.shared = true; sw.dirty = true;
+        sw.shared = true;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -790,12 +807,12 @@ __device__ __forceinline__ void steal_step(WalkRay& r, WalkStack& st, int& cur, 
 }
 
 __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, WalkStack& st, float& t_min, int& best_slot,
-                                             const CoopLeaf& cl, unsigned long long* wbest, int lane, bool walk) {
+                                             const CoopLeaf& cl, int lane, bool walk) {
     const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
     const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
     WalkRay r;
     r.start(o, d, t_min);
-    int cur = walk ? 0 : WALK_DONE;                            // (lanes whose ray misses the mesh box help with the leaf steps)
+    int cur = walk ? 0 : WALK_DONE;                            // (lanes whose ray misses the mesh box help: leaf steps, takeovers)
     st.sp = 0; st.bot = 0;
 #ifdef AIPT_TRACE_STATS
     int my_visits = 0;
@@ -806,9 +823,9 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
     if (AIPT_POOL_COOP_LEAF) {
         // wave-level "while-while": every lane descends to its next leaf, then ALL 64 lanes share the leaves' triangle tests;
         // idle lanes take over parts of the busy lanes' walks (steal_step)
-        const unsigned long long key0 = walk_key(r);
-        SplitWalk sw{wbest, lane, false, walk};
-        wbest[lane] = key0;
+        const unsigned long long key0 = ((unsigned long long)__float_as_uint(t_min) << 32);
+        SplitWalk sw{lane, false};
+        cl.best[lane] = key0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -817,25 +834,15 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
                 steal_step(r, st, cur, sw, cl, lane);
                 if (!__ballot(cur >= 0)) break;
                 if (cur >= 0) {
-                    if (sw.shared) {                           // the other parts of this ray's walk may have found something nearer
-                        const unsigned long long wb = sw.wbest[sw.owner];
-                        const float tb = __uint_as_float((unsigned)(wb >> 32));
-                        if (tb < r.t_min) { r.t_min = tb; r.best_face = (int)(unsigned)wb; }   // (a real face: the word only falls through faces)
-                    }
+                    split_refresh(r, sw, cl);
                     STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
                     walk_node(nodes, r, st, cur);
                 }
             }
             if (!__ballot(cur != WALK_DONE)) break;
-            const float t_before = r.t_min;
-            coop_leaf_step(tris, r, st, cur, cl, lane);
-            if (sw.shared && r.t_min < t_before) atomicMin(&sw.wbest[sw.owner], walk_key(r));
+            coop_leaf_step<true>(tris, r, st, cur, cl, lane, sw.owner);
         }
-        // (every part has reported: a lane only turns idle through steal_step's first lines, and the loop ends with all lanes idle)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const unsigned long long res = wbest[lane];
+        const unsigned long long res = cl.best[lane];          // (every leaf step ended behind a wave barrier)
         best_slot = -1;
         if (walk && res != key0) {                             // a face strictly below the bound (or, between faces, the lowest index)
             t_min = __uint_as_float((unsigned)(res >> 32));
@@ -927,8 +934,14 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
     int cur = WALK_DONE, lid = -1;
     bool exhausted = pool_n == 0;
     st.sp = 0; st.bot = 0;
+    // the tail (pool exhausted): split walks -- the rays still under way keep their lanes' result words (cl.best[lane], this wave's
+    // slice: no unsplit leaf step needs it any more) until the wave is done, and idle lanes take over parts of their walks
+    constexpr unsigned long long KEY_NONE = (unsigned long long)0x7f7fffffu << 32;      // (FLT_MAX, 0): no face
+    bool split = false;
+    int tail_lid = -1;
+    SplitWalk sw{lane, false};
     while (true) {
-        if (cur == WALK_DONE && lid >= 0) {                         // finished since the last look: hand the result over
+        if (!split && cur == WALK_DONE && lid >= 0) {               // finished since the last look: hand the result over
             s_res[lid] = r.best_slot;                               // (the distance comes back with the winner's full test)
             lid = -1;
         }
@@ -951,6 +964,17 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
             }
             exhausted = base + nidle >= pool_n;
         }
+#if AIPT_POOL_TAIL_BOTH
+        if (exhausted && !split) {                                  // (wave-uniform) from here on: split walks
+            split = true;
+            tail_lid = lid;                                         // (-1: this lane holds no ray)
+            lid = -1;
+            cl.best[lane] = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#endif
         // one step for the lanes of one kind: inner nodes, unless POOL_LEAF lanes wait at a leaf (or nobody is at a node).
         // (The fused walk's "descend until every lane holds a leaf" keeps a lane that found its leaf early idle for the
         // whole descent of the others; with refilled lanes at every depth that would be most of the time.)
@@ -963,10 +987,13 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
 #if AIPT_POOL_TAIL_BOTH
         // Once the pool has run dry the wave's last rays are a latency chain (42 % of a later bounce's node steps run after that,
         // 30 % with at most 8 lanes at a node): nobody waits for company any more -- every lane at a leaf gets its (cheap,
-        // cooperative) leaf step and every lane at a node its node step in the same trip.
+        // cooperative) leaf step and every lane at a node its node step in the same trip -- and [r5] the idle lanes take over
+        // parts of the remaining walks (steal_step)
         if (exhausted) {
-            if (nl) coop_leaf_step(tris, r, st, cur, cl, lane);
+            steal_step(r, st, cur, sw, cl, lane);
+            if (__ballot(cur < 0 && cur != WALK_DONE)) coop_leaf_step<true>(tris, r, st, cur, cl, lane, sw.owner);
             if (cur >= 0) {
+                split_refresh(r, sw, cl);
                 STAT_ADD(0, 1); STAT_WAVE(1);
                 walk_node(nodes, r, st, cur);
             }
@@ -974,7 +1001,7 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
         }
 #endif
         if (nl >= POOL_LEAF || !any_node) {
-            if (AIPT_POOL_COOP_LEAF) coop_leaf_step(tris, r, st, cur, cl, lane);
+            if (AIPT_POOL_COOP_LEAF) coop_leaf_step<false>(tris, r, st, cur, cl, lane, lane);
             else if (cur < 0 && cur != WALK_DONE) {
                 walk_leaf(tris, r, cur);
                 cur = st.empty() ? WALK_DONE : st.pop();
@@ -984,6 +1011,11 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
             walk_node(nodes, r, st, cur);
         }
     }
+    if (tail_lid >= 0) {                                            // the rays of the tail: their words' faces (every leaf step ended behind a wave barrier)
+        const unsigned long long res = cl.best[lane];
+        s_res[tail_lid] = res != KEY_NONE ? p.fslot[(unsigned)res] : -1;
+    }
+    if (!split && lid >= 0) s_res[lid] = r.best_slot;               // (AIPT_POOL_TAIL_BOTH = 0 builds)
 }
 
 // ---------------------------------------------------------------------------------------------- the bounce kernel
@@ -991,8 +1023,11 @@ __device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_poo
 #ifndef AIPT_TRACE_OCC
 #define AIPT_TRACE_OCC 1
 #endif
+#ifndef AIPT_WALK_OCC
+#define AIPT_WALK_OCC 1      // workgroups per CU (= waves per SIMD) the un-pooled later-bounce instantiation is compiled for
+#endif
 template <bool FIRST, bool MESH, bool POOL = false>
-__global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
+__global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
     static_assert((MESH && !FIRST) || !POOL, "the pool holds the mesh walks of the later bounces (bounce 0: coherent camera rays)");
     __shared__ int s_wave[4];
     __shared__ int s_pool_n, s_head;
@@ -1060,7 +1095,6 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     __shared__ unsigned long long s_best[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
     __shared__ int s_slot[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
     __shared__ float2 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 768 : 1];
-    __shared__ unsigned long long s_wbest[MESH && !POOL && AIPT_POOL_COOP_LEAF ? 256 : 1];   // split walks of the un-pooled kernel: per wave, per owner lane
     const CoopLeaf cl{s_pairs + (MESH && AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
                       s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 192 : 0)};
     if (POOL) {
@@ -1216,7 +1250,7 @@ __global__ __launch_bounds__(256, AIPT_TRACE_OCC) void trace_bounce(const TraceP
     if (MESH && !POOL && __syncthreads_or(want_walk)) {           // (workgroup-uniform: the cooperative leaf step's LDS slices are per wave)
         int best_slot = -1;
         WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0, 0};
-        bvh4_nearest(p, o, d, st, t_min, best_slot, cl, s_wbest + (MESH && !POOL && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), lane, want_walk);
+        bvh4_nearest(p, o, d, st, t_min, best_slot, cl, lane, want_walk);
         if (best_slot >= 0) {
             // the winning face, once: the reference's full test gives its hit point and shading normal (and the same t)
             DevFace f;

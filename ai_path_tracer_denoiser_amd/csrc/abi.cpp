@@ -4,6 +4,7 @@
 // pathtrace.cu:525 + main.cpp:104-105).
 #include "internal.h"
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -257,7 +258,7 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
         AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_prefetched, 0));
         for (int b = 0; b < 2; b++) if (ctx->denoised_valid[b]) AIPT_HIP(ctx, hipStreamWaitEvent(dn, ctx->ev_denoised[b], 0));
     }
-    rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw, false, dn != ctx->stream ? dn : nullptr);
+    rc = aipt::denoise_run(ctx, ctx->d_gbuf, d_out3, dn_flags, ctx->fh, ctx->fw, false, dn != ctx->stream ? dn : nullptr, ctx->st_dn_cus);
     if (rc) return rc;
     AIPT_HIP(ctx, hipEventRecord(ctx->ev_denoised[ctx->front], dn));
     ctx->denoised_valid[ctx->front] = true;
@@ -438,12 +439,18 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
     if (iter != 1) return fail(ctx, AIPT_E_INVALID, "aipt_frame_prefetch: only iter == 1 frames can be prefetched (iter %d)", iter);
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->st_trace) {
-        // two streams on disjoint CUs: the first AIPT_PREFETCH_TRACE_CUS (default: half) for the trace, the rest for the denoiser
+        // two streams on disjoint CUs: the first AIPT_PREFETCH_TRACE_CUS for the trace, the rest for the denoiser.  Mask bit i is one
+        // CU of XCD i % 8, and a launch's workgroup b still starts on XCD b & 7 (tools/ubench/cumask.hip), so both shares are whole
+        // multiples of 8 -- of 32, in fact: the persistent conv kernel takes one workgroup per enabled CU (denoise_run's on_cus),
+        // and with a CU count per XCD that is not a multiple of 4 (its shader engines) some of them wait for a second round
+        // (measured: trace share 64 / 72 / 80 / 88 / 96 / 104 / 112 / 120 / 128 CUs = 631 / 639 / 625 / 661 / 808 / 601 / 562 / 596 /
+        // 719 frames/s).  Default 3/8 of the chip [r5: the split walks made the trace the shorter stage; rounds 2-4: half]
         hipDeviceProp_t prop;
         AIPT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
         const int ncu = prop.multiProcessorCount;
         static const int env_cus = getenv("AIPT_PREFETCH_TRACE_CUS") ? atoi(getenv("AIPT_PREFETCH_TRACE_CUS")) : 0;
-        const int nt = env_cus > 0 && env_cus < ncu ? env_cus : ncu / 2;
+        const int want = env_cus >= 32 && env_cus <= ncu - 32 ? env_cus : ncu * 3 / 8;
+        const int nt = ncu >= 64 ? std::max(32, want & ~31) : ncu / 2;
         std::vector<uint32_t> mt((ncu + 31) / 32, 0u), md((ncu + 31) / 32, 0u);
         for (int c = 0; c < ncu; c++) (c < nt ? mt : md)[c / 32] |= 1u << (c % 32);
         if (hipExtStreamCreateWithCUMask(&ctx->st_trace, (uint32_t)mt.size(), mt.data()) != hipSuccess ||
@@ -452,7 +459,7 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
             (void)hipGetLastError();
             if (ctx->st_trace) hipStreamDestroy(ctx->st_trace);
             ctx->st_trace = ctx->stream; ctx->st_dn = nullptr;
-        }
+        } else ctx->st_dn_cus = ncu - nt;
     }
     const int back = ctx->front ^ 1;
     hipStream_t ts = ctx->st_trace;

@@ -1040,7 +1040,6 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
             posmask |= (c >= g.cout || !(g.pool_gamma[c] < 0.0f)) ? (1u << k) : 0u;
         }
     }
-    float bsum1 = 0.f, bsum2 = 0.f;                            // BN sums of this lane's channel over all items of the wave (a fixed order)
 
     // ---- prefetch cursor: (item, chunk, halo row) PF rows ahead of the consumer; the first rows are requested before the prologue
     int pf_it = it, pf_c = 0, pf_y0 = 0;
@@ -1303,22 +1302,24 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
         if (g.stat) {
 #pragma unroll
             for (int k = 0; k < 16; k++) { s1[k] = lane_ok ? s1[k] : 0.f; s2[k] = lane_ok ? s2[k] : 0.f; }
-            bsum1 += halfwave_sum16(s1, m);
-            bsum2 += halfwave_sum16(s2, m);
+            // [r5] committed item by item to the workgroup's fixed-point accumulators (integer adds): the sums do not depend on
+            // which wave of which workgroup ran which item -- the same bits on any number of CUs (aipt_frame_prefetch runs this
+            // kernel on a CU-masked stream with fewer workgroups); measured free against one fp32 running sum per wave
+            const float h1 = halfwave_sum16(s1, m), h2 = halfwave_sum16(s2, m);
+            if (m < 16) {                                      // lanes m < 16 of both halves hold channel (k & 3) + 8 (k >> 2) + 4 gq, k as in halfwave_sum16
+                const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
+                int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+                if (g.d2s) cl = cl < 16 ? (cl & 3) : 31;       // a channel's four children share its sums (slot 31: the unused virtual channels, all zero)
+                const BnFix fx = bn_fix((double)h1), fq = bn_fix((double)h2);
+                unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
+                atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
+                atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
+            }
         }
     }
 
-    // ---- BN sums of the workgroup: lanes m < 16 of both halves hold channel (k & 3) + 8 (k >> 2) + 4 gq, k as in halfwave_sum16
+    // ---- BN sums of the workgroup -> the layer's table
     if (g.stat) {
-        if (m < 16) {
-            const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
-            int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
-            if (g.d2s) cl = cl < 16 ? (cl & 3) : 31;           // a channel's four children share its sums (slot 31: the unused virtual channels, all zero)
-            const BnFix fx = bn_fix((double)bsum1), fq = bn_fix((double)bsum2);
-            unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
-            atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
-            atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
-        }
         __syncthreads();
         if (tid < 32 && n0 + tid < (g.d2s ? g.d2s : g.cout)) {
             unsigned long long* dst = reinterpret_cast<unsigned long long*>(g.stat + ((size_t)(blockIdx.x % NSLOT) * g.sc + n0 + tid) * BN_WORDS);
@@ -1612,6 +1613,7 @@ struct DenoiseState {
     bool hidden_valid = false;
     int impl = AIPT_DN_IMPL_MFMA_F16X3;
     int num_cus = 256;
+    int run_cus = 256;                 // CUs the forward pass being enqueued may use (fewer than num_cus on aipt_frame's CU-masked denoiser stream)
     // kernel selection of the split-fp16 implementations (aipt_denoise_set_option; level sizes in pixels)
     long long opt_r_minpix = 200000;   // >= : conv3x3_f16x3r (register-staged, persistent)
     long long opt_f16_minpix = 14000;  // >= : conv3x3_f16x3 with 8-row tiles, below: 4-row tiles
@@ -1839,7 +1841,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
         gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
-        const int r_wpg = s->num_cus / 8;
+        const int r_wpg = s->run_cus / 8;
         if ((long long)gh.H * gh.W >= s->opt_r_minpix && gh.nchunks <= RR_MAXCH && r_wpg >= 1 && !(gh.H & 1) && !(gh.W & 1) && L.d_wsplit1_d2s[0] &&
             (long long)H * W * 16 < (1ll << 31) &&
             f16_range_ok(s, batch, nstat, 4000.0)) {
@@ -1900,7 +1902,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             return fail(ctx, AIPT_E_STATE, "layer %d: a planar conv input must be the untransformed network input", li);
         // the levels of >= opt_r_minpix pixels: persistent register-staged kernel (conv3x3_f16x3r), when the group's weights fit
         // LDS and the normalised activations provably fit its operand range (f16_range_ok)
-        const int r_groups = L.coutp32 / 32, r_wpg = (s->num_cus / 8) / r_groups;
+        const int r_groups = L.coutp32 / 32, r_wpg = (s->run_cus / 8) / r_groups;
         if ((long long)H * W >= s->opt_r_minpix && gh.nchunks <= (w16 ? 2 * RR_MAXCH : RR_MAXCH) && r_wpg >= 1 && !(H & 1) && !(W & 1) &&
             (long long)pad16(L.cout) * H * W * 4 < (1ll << 31) &&      // its output descriptors address the tensor with 31-bit offsets
             (gh.a.planar || f16_range_ok(s, batch, nstat, 4000.0))) {
@@ -1923,7 +1925,7 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             // all fit the chip at once: the launch then lasts one workgroup's chain of chunk steps, which the split shortens
             // (dec4.c1 28 -> 23 us; enc4.* with 345 workgroups would need two rounds: 8-row tiles stay)
             const long long wg4 = (long long)((W + 31) / 32) * ((H + 3) / 4) * (L.coutp32 / 32);
-            const bool one_round4 = s->opt_ky_split && wg4 <= s->num_cus;
+            const bool one_round4 = s->opt_ky_split && wg4 <= s->num_cus;       // (the device's CUs, not a masked stream's: the selection must not change the bits)
             const int rows = gh.a.planar ? 8 : ((long long)H * W >= s->opt_f16_minpix && !one_round4) ? 8 : 4;
             const dim3 grid((W + 31) / 32, (H + rows - 1) / rows, L.coutp32 / 32);
             gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = grid.z;
@@ -2274,7 +2276,7 @@ int aipt_denoise(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t fla
 // on the stream of its activation set (set 0: the context's stream, set k: ctx->pipe[k-1]) and waits, level by level, for the
 // hidden states of the frame before it; the caller forks / joins the streams around a run of such frames.
 int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined,
-                      hipStream_t on) {
+                      hipStream_t on, int on_cus) {
     DenoiseState* s = state(ctx);
     if (!s->have_weights) return fail(ctx, AIPT_E_STATE, "aipt_denoise: no weights loaded");
     if (!s->H) return fail(ctx, AIPT_E_STATE, "aipt_denoise: call aipt_denoise_configure first");
@@ -2297,6 +2299,9 @@ int aipt::denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_
         AIPT_HIP(ctx, hipStreamWaitEvent(st, ctx->ev_traced, 0));
     s->cur = st;
     s->aset = a;
+    // a CU mask enables the same number of CUs on every XCD and workgroup b still starts on XCD b & 7 (tools/ubench/cumask.hip): the
+    // persistent kernel takes one workgroup per ENABLED CU (sized for all CUs it would run two rounds of statically dealt items)
+    s->run_cus = on && on_cus >= 8 && on_cus <= s->num_cus ? on_cus & ~7 : s->num_cus;
     // a forward pass whose launches are being timed (aipt_denoise_profile_*) runs alone: the other streams drain before it
     // and resume after it, so that an event pair brackets one kernel and not its overlap with another frame's
     const bool timed = pipelined && s->prof_mask && s->prof_calls < s->prof_max && s->prof_seen % s->prof_every == 0;

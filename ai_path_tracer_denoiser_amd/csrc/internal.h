@@ -45,6 +45,7 @@ struct aipt_ctx {
     // `st_dn` -- two streams restricted to DISJOINT sets of CUs (hipExtStreamCreateWithCUMask): a scheduling choice (a single
     // frame's trace does not fill the chip; sharing all CUs measured slower), no longer a correctness fence
     hipStream_t st_trace = nullptr, st_dn = nullptr;
+    int st_dn_cus = 0;                                // CUs enabled on st_dn
     hipStream_t st_lane1 = nullptr;                   // aipt_frames: the second half of a call's frames is traced here, beside the first
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
     // aipt_frames: the denoiser passes of consecutive frames rotate over `stream` and the `pipe` streams (denoise_run,
@@ -123,7 +124,7 @@ inline hipError_t sync_streams(aipt_ctx* ctx) {
 }
 // aipt_denoise with the planar output cropped to out_h x out_w (<= the configured size)
 int denoise_run(aipt_ctx* ctx, const float* d_in10, float* d_out3, uint32_t flags, int out_h, int out_w, bool pipelined = false,
-                hipStream_t on = nullptr);
+                hipStream_t on = nullptr, int on_cus = 0);       // on: a CU-masked stream with on_cus CUs enabled
 void trace_destroy(aipt_ctx* ctx);
 int trace_enable_lanes(aipt_ctx* ctx);        // aipt_frames_configure: allocate the side lane of two-lane traces and warm its stream
 bool trace_lanes_ready(aipt_ctx* ctx, int nframes);

@@ -31,7 +31,7 @@
  *                               counter then belongs to one kernel; tools/collect_evidence.sh)
  *   AIPT_TRACE_POOL=0 / 1       batched traces: never / always pool the BVH walks of a workgroup's paths (default: from 4 frames
  *                               per launch on)
- *   AIPT_PREFETCH_TRACE_CUS=n   aipt_frame_prefetch: CUs of the trace stream's mask (default: half of the chip)
+ *   AIPT_PREFETCH_TRACE_CUS=n   aipt_frame_prefetch: CUs of the trace stream's mask, a multiple of 32 (default: 3/8 of the chip)
  *   AIPT_TRACE_LANES=1          aipt_frames: trace a call's frames with ONE set of launches instead of two half-batches side by
  *                               side on two streams (default 2)
  * Everything else (kernel selection, tile sizes) is an explicit ABI option (aipt_denoise_set_option) or a debug-build hook
@@ -286,11 +286,12 @@ int aipt_frame(aipt_ctx* ctx, const aipt_camera* cam, int iter, int depth, uint3
                float* d_out3);
 /* Throughput pipelining for frame-by-frame hosts (no reference equivalent: runCuda traces and denoises strictly in turn,
  * main.cpp:143-163).  Starts the path trace of the NEXT frame into the context's back G-buffer on a stream restricted to
- * half of the CUs; the following aipt_frame with an identical (cam, iter, depth, trace_flags) consumes it instead of tracing
- * and runs its denoise on a stream restricted to the OTHER half, so that the next prefetch's trace runs beside it.  A
- * different request drops the prefetch.  Results are identical to frames without it (one frame of latency, +37 % frames/s
- * on the mesh configuration; on scenes whose trace is cheap the halved denoiser costs more than the overlap gains: do not
- * prefetch there).  The two streams use DISJOINT CUs as a scheduling choice: a single frame's trace does not fill the chip, and
+ * 3/8 of the CUs; the following aipt_frame with an identical (cam, iter, depth, trace_flags) consumes it instead of tracing
+ * and runs its denoise on a stream restricted to the OTHER CUs, so that the next prefetch's trace runs beside it.  A
+ * different request drops the prefetch.  Results are identical to frames without it (one frame of latency, +27 % frames/s
+ * on the mesh configuration: 782 against 616; on scenes whose trace is cheap the reduced denoiser costs more than the overlap
+ * gains: do not prefetch there).  Round 5: 96 CUs trace : 160 CUs denoise (rounds 2-4: halves); the persistent conv kernel is
+ * launched with one workgroup per CU of ITS share (same bits at any workgroup count).  The two streams use DISJOINT CUs as a scheduling choice: a single frame's trace does not fill the chip, and
  * sharing all CUs measured slower.  (In round 2 the split was also a fence: a bounce kernel sharing a CU with the split-fp16
  * conv kernel returned wrong values in a few lanes -- packed-fp32 VALU instructions beside gapped fp16 MFMAs, a gfx950 erratum;
  * the library is built without packed fp32 since round 3 and no kernel of it can be the victim)

@@ -62,6 +62,44 @@ def test_duplicate_faces_keep_the_lowest_index(ctx):
     assert (m_ref == a).any() and (m_ref == b).any()
 
 
+def test_split_walks_resolve_ties_across_stolen_subtrees(ctx):
+    """[r5] Split walks: idle lanes take over subtrees of a busy lane's walk and all parts of a ray meet in one (t, face index)
+    minimum.  Ten copies of every face, materials alternating, spread over the whole index range: a group of equal-distance
+    faces exceeds a leaf (7 faces) and lies in different leaves / subtrees, so the lowest index has to win ACROSS the parts of a
+    walk -- single frames (every lane of a 48 x 40 image's waves has idle neighbours) and a batch (splitting in the pooled walk's
+    tail), against the oracle's index-ordered loop (strict t_min > t, pathtrace.cu:261)."""
+    import oracle
+    sc = oracle.OracleScene.parse(CORNELL, res=(48, 40), depth=3)
+    mats = [add_stone_material(sc) for _ in range(4)]
+    for k, m in enumerate(mats):
+        sc.materials[m].color[:] = [.2 + .2 * k, .9 - .2 * k, .3]
+    base, lb, ub = synth.make_atrium_mesh(2048, 3, material=mats[0])
+    copies = []
+    for k in range(10):
+        c = base.copy()
+        c["materialid"] = np.asarray(mats)[(np.arange(len(c)) + 3 * k) % 4]   # a face's copies differ in material: the winner of a tie shows
+        copies.append(np.roll(c, 37 * k) if k % 2 else c[::-1].copy())
+    faces = np.concatenate(copies)
+    sc.set_mesh(faces, lb, ub)
+    g_ref, n_ref, m_ref = sc.pathtrace()
+    g, n, m = gpu_trace(ctx, sc, 3)
+    assert np.array_equal(m, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist()
+    assert np.array_equal(g, g_ref)
+    assert len(set(m_ref[np.isin(m_ref, mats)].tolist())) >= 3   # ties were won by copies of several materials
+    # the same camera eight times in one batched trace (pooled walks, split in their tail): every frame = the single frame
+    import torch
+    from tests.gpu_util import to_api_scene
+    cam = to_api_scene(sc)[4]
+    ctx.trace_configure_batch(48, 40, 8)
+    gb = torch.zeros(8, 10, 40, 48, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pathtrace_batch([cam] * 8, 1, 3, gb)
+    ctx.sync()
+    gb = gb.cpu().numpy()
+    for f in range(8):
+        assert np.array_equal(gb[f], g_ref), f
+
+
 def test_full_size_sponza_like_mesh_runs_and_is_consistent(ctx):
     """BASELINE.json configs[2] shape: 262144-triangle mesh, 1280x720, depth 8 (BVH only: brute force is O(F) per ray)."""
     sc = _scene((1280, 720), 8, 262144)

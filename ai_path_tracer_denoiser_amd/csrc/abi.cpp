@@ -449,8 +449,10 @@ int aipt_frame_prefetch(aipt_ctx* ctx, const aipt_camera* cam, int iter, int dep
         AIPT_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
         const int ncu = prop.multiProcessorCount;
         static const int env_cus = getenv("AIPT_PREFETCH_TRACE_CUS") ? atoi(getenv("AIPT_PREFETCH_TRACE_CUS")) : 0;
-        const int want = env_cus >= 32 && env_cus <= ncu - 32 ? env_cus : ncu * 3 / 8;
-        const int nt = ncu >= 64 ? std::max(32, want & ~31) : ncu / 2;
+        const int want = env_cus >= 8 && env_cus <= ncu - 32 ? env_cus : ncu * 3 / 8;
+        // (the DENOISER's share in whole multiples of 32 = 4 CUs per XCD; the trace takes the rest, a multiple of 8 on a chip of 8 k CUs)
+        const int dn = std::min(ncu - 8, std::max(32, (ncu - want + 16) / 32 * 32));
+        const int nt = ncu >= 64 && (ncu & 7) == 0 ? ncu - dn : ncu / 2;
         std::vector<uint32_t> mt((ncu + 31) / 32, 0u), md((ncu + 31) / 32, 0u);
         for (int c = 0; c < ncu; c++) (c < nt ? mt : md)[c / 32] |= 1u << (c % 32);
         if (hipExtStreamCreateWithCUMask(&ctx->st_trace, (uint32_t)mt.size(), mt.data()) != hipSuccess ||

@@ -16,7 +16,10 @@
 //    writes (planes 3-9, already h-flipped) and finalGather+copy_data: a path deposits its colour into planes 0-2
 //    the moment its remainingBounces reaches 0 (light, miss, or depth exhausted -- SURVEY F9).
 //  * Mesh: a 4-wide BVH with 8-bit child boxes (64-byte nodes) walked front to back on a per-lane LDS stack, 48-byte leaf
-//    triangle records, the winning face fetched once after the walk (bvh.cpp).
+//    triangle records, the winning face fetched once after the walk (bvh.cpp).  A leaf's triangles are tested by all 64 lanes
+//    of the wave (coop_leaf_step); batched traces pool a workgroup's rays and refill idle lanes (pool_walk); idle lanes that
+//    cannot be refilled take over subtrees of the busy lanes' walks, all parts of a ray meeting in one (t, face index)
+//    minimum (steal_step): the result never depends on which lane walked what.
 //
 // Arithmetic is plain IEEE fp32 (this file is compiled with -ffp-contract=off, correctly rounded divide/sqrt), in the
 // statement order of the reference/GLM sources, so the output matches the CPU restatement used by the tests bit for

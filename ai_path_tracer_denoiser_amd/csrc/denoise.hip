@@ -26,6 +26,8 @@
 #include <cmath>
 #include <cstring>
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 
 namespace aipt {
 
@@ -952,8 +954,22 @@ __global__ __launch_bounds__(NWV * KYS * 64, KYS == 3 ? 3 : NWV == 8 ? 4 : 2) vo
 constexpr int RR_PX = 30;                                     // valid output pixels of an item's row (32 loaded)
 constexpr float XS1 = 16.0f, WS1 = 128.0f;
 constexpr int RR_MAXCH = 8;                                   // chunks whose weights fit LDS (fp16-weight mode: twice as many)
+#ifdef AIPT_R_CLOCK
+// debug builds (tools/build_variant.sh ... -DAIPT_R_CLOCK): per layer {first wave start, last wave start, first wave end, last wave
+// end, after the prologue barrier (last), main loop end (last)} on the chip-wide 100 MHz clock, one wave's shader-clock count and its
+// 100 MHz count: the timeline of a forward pass without a profiler (run_conv prints it after the last layer)
+__device__ unsigned long long g_rclk[32][8];
+__device__ unsigned long long g_rclk_w[32][4096][4];       // per wave: start, after the prologue barrier, main loop end, (unused)
+#endif
+#ifndef AIPT_R_WAVES
+#define AIPT_R_WAVES 12                                       // waves per workgroup of the C4-input instantiations (A/B builds: 8)
+#endif
+#ifndef AIPT_R_PF
+#define AIPT_R_PF 3                                           // halo rows of load lookahead (the register ring) of the C4-input instantiations
+#endif
+constexpr int R_NWV = AIPT_R_WAVES, R_PF = AIPT_R_PF;
 static inline size_t convr_lds_bytes(int nchunks, bool w16) {
-    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * BN_WORDS * 8 + 32;
+    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * BN_WORDS * 8 + 64;
 }
 
 // lo half of the split: the fp16 roundings of v0 - hi.lo and v1 - hi.hi, packed, in two mixed-precision FMAs (instead of two
@@ -994,6 +1010,33 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
     return a1;
 }
 
+// ---- the software-pipelined main loop of conv3x3_f16x3r [r6] (tools/ubench/mfma_fill.hip, profiles/r06_ubench_mfma_fill.txt)
+// Measured in CYCLES: one wave hides <= 5 single-issue instructions behind every v_mfma_f32_32x32x16_f16 (33-37 cycles per MFMA
+// for 0-5 fillers BETWEEN consecutive MFMAs, three waves per SIMD: 32.3-33.7), while the same instructions in bursts between
+// clusters of MFMAs -- what hipcc makes of the row-by-row source: 45 VALU, then MFMAs with a `ds_read; s_waitcnt lgkmcnt(0)` before
+// each -- cost 39-40 cycles per MFMA at 4-5 fillers with three waves and 53-57 with one.  "VALU time adds to MFMA time" (DESIGN
+// rounds 3-5) was an artefact of measuring MFMAs-THEN-VALU in one in-order wave, in nanoseconds across bodies that clock differently.
+// So the chunk body is written as ONE instruction stream in issue order: after every MFMA of halo row h a few instructions of
+//   * the transform of row h + 1 (BN affine, LeakyReLU, fp16 hi/lo split: 36), its BN coefficients (4 LDS reads) and its wave_shr
+//     column shift (8 DPP moves), this row's wave_shl shift (8), the global loads of the row four ahead (2), and
+//   * the weight fragments of the NEXT (tap, output row) pair (2 LDS reads into the other of two register sets),
+// pinned by a __builtin_amdgcn_sched_barrier(0) on either side (hipcc then only allocates registers and places s_waitcnt / s_nop).
+// Same MFMAs on the same operands in the same order as the row-by-row loop: the same bits.
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+constexpr int swp_nky(int h) { return (h == 0 || h == 5) ? 1 : (h == 1 || h == 4) ? 2 : 3; }   // tap rows halo row h of a 4-row item serves
+constexpr int swp_ky0(int h) { return h <= 3 ? 0 : h - 3; }                                    // the first of them (output row r = h - ky)
+constexpr int swp_tr0(int h) { int s = 0; for (int k = 0; k < h; k++) s += 3 * swp_nky(k); return s; }   // (tap, row) pairs before row h
+constexpr int swp_row_of(int G) { G %= 36; int h = 0; while (G >= 3 * swp_nky(h)) { G -= 3 * swp_nky(h); h++; } return h; }   // halo row of a step's pair G
+constexpr int swp_tap_of(int G) {                                                             // its tap ky * 3 + kx
+    G %= 36;
+    const int h = swp_row_of(G), t = G - swp_tr0(h), nky = swp_nky(h);
+    return (swp_ky0(h) + t % nky) * 3 + t / nky;
+}
+constexpr int SWP_OPS = 59;        // stream positions of a row region: 0 select, 1-4 coefficients, 5-12 shl, 13-48 transform, 49-50 loads, 51-58 shr
+
 // RR_ROWS = output rows of an item: 4 on the levels with many items; 2 on the small levels (twice the items, half the serial
 // chain of steps per item: those launches last as long as one wave's item).
 // PLANAR: source a is the planar network input [C][h][w], C <= 16 (one chunk): eight 4-byte loads per lane and halo row instead of
@@ -1003,19 +1046,32 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
 // below 2^-29, fine for normalised activations, not for a first-hit distance in centimetres).  One chunk: the layer is bound by
 // its 158 MB, the second accumulator is free (8 waves per CU).
 template <bool W16, int NWV, int PF, bool WC, int RR_ROWS = 4, bool PLANAR = false>
-__global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const ConvArgsH g) {
+__global__ __launch_bounds__(NWV * 64, (PLANAR || NWV <= 8) ? 2 : 3) void conv3x3_f16x3r(const ConvArgsH g) {
     constexpr int RR_NT = NWV * 64, RR_WAVES = NWV;
     static_assert((RR_ROWS + 2) % PF == 0, "the ring slot of a halo row must be static");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int WB = W16 ? WSLAB / 2 : WSLAB;                // LDS bytes of a chunk's weights
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 31, gq = lane >> 5;   // (wave: an SGPR, so is everything derived from it)
     const int nch = g.nchunks, ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up;
+#ifdef AIPT_R_SWP
+    constexpr bool SWP = !PLANAR && !WC && RR_ROWS == 4 && (PF == 3 || PF == 6);   // A/B builds: the software-pipelined main loop (see swp_* above)
+#else
+    constexpr bool SWP = false;                                // the row-by-row main loop: equally fast, 26 registers fewer (tools/experiments/README.md, round 6)
+#endif
+    // BN coefficient table.  Row-by-row loop: a[nch][16], b[nch][16].  SWP: one 64-byte block {a[8], b[8]} per (chunk, k-group), so
+    // that ONE address select (block or the zero block) serves a row's four 16-byte reads
     float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
     float* bias_s = tab_b + nch * KH;                          // [32], times the operand scaling (2^4 2^7 = 2^11, or 2^-4 with PLANAR): the accumulators start from it
     long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][BN_WORDS]
-    const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [8]: the BN coefficients of out-of-image pixels
+    const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [16]: the BN coefficients of out-of-image pixels
 
+#ifdef AIPT_R_CLOCK
+    // debug builds: the shader clock this launch ran at (s_memtime follows DVFS, s_memrealtime is 100 MHz), printed by one wave
+    const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* const clk_w = g_rclk_w[g.ablate & 31][(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & 4095];
+    if ((threadIdx.x & 63) == 0) clk_w[0] = clk_r0;
+#endif
     // ---- workgroup -> (XCD, output-channel group); XCD b & 7 owns a contiguous band of item rows
     const int b = blockIdx.x, xcd = b & 7, slot = b >> 3, groups = g.groups;
     const int wpg = (int)(gridDim.x >> 3) / groups;            // workgroups per (XCD, group)
@@ -1044,6 +1100,11 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
     // ---- prefetch cursor: (item, chunk, halo row) PF rows ahead of the consumer; the first rows are requested before the prologue
     int pf_it = it, pf_c = 0, pf_y0 = 0;
     unsigned pf_v0 = 0, pf_v1 = 0;                             // this lane's byte offsets inside a chunk's row: pixel + its two channel quads
+    const unsigned char* pf_base = nullptr;                    // the cursor's chunk: first of its four channel-quad planes (scalar)
+    auto pf_chunk = [&]() {
+        const bool fa = pf_c < ca16;
+        pf_base = reinterpret_cast<const unsigned char*>(fa ? g.a.p : g.b.p) + (size_t)(fa ? pf_c : pf_c - ca16) * 4 * plane16;
+    };
     auto pf_item = [&](int item) {                             // geometry of the cursor's item
         const int rb = item / tiles_x, tx = item - rb * tiles_x;
         pf_y0 = (rb0 + rb) * RR_ROWS;
@@ -1051,13 +1112,13 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
         pf_v0 = PLANAR ? (unsigned)x * 4u : (unsigned)(up ? (x >> 1) : x) * 16u + (unsigned)(2 * gq) * plane16;
         pf_v1 = pf_v0 + plane16;
     };
-    f32x4 raw[PF][2];
+    f32x4 raw[PF][2] = {};
     auto issue = [&](int slot, int hp) {                       // the two channel quads of this lane's pixel in halo row hp
+#ifdef AIPT_R_NOLOADS
+        return;                                                // (ablation builds: results are wrong by design)
+#endif
         const int y = min(max(pf_y0 - 1 + hp, 0), H - 1);
         const unsigned roff = (unsigned)((up ? (y >> 1) : y) * sw) * 16u;
-        const bool fa = pf_c < ca16;
-        const int cl = fa ? pf_c : pf_c - ca16;
-        const ConvSrc& sr = fa ? g.a : g.b;
         if (PLANAR) {
             // channel 8 gq + t of this lane's pixel (past the last channel: the last one again; its BN coefficients are (0, 0))
             const unsigned planeb = plane16 >> 2;                                  // bytes of one channel plane
@@ -1070,12 +1131,13 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
             return;
         }
         // (tensors are allocated in whole 16-channel chunks: no clamping of pad quads; scalar row base + per-lane offset)
-        const unsigned char* rowp = reinterpret_cast<const unsigned char*>(sr.p) + ((size_t)cl * 4 * plane16 + roff);
+        const unsigned char* rowp = pf_base + roff;
         raw[slot][0] = *reinterpret_cast<const f32x4*>(rowp + pf_v0);
         raw[slot][1] = *reinterpret_cast<const f32x4*>(rowp + pf_v1);
     };
     if (it < nitems) {
         pf_item(it);
+        pf_chunk();
 #pragma unroll
         for (int h = 0; h < PF; h++) issue(h, h);
     }
@@ -1083,11 +1145,21 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
     // ---- prologue: weights of all chunks, BN coefficient table, bias -> LDS
     {
         const unsigned char* src = g.wsplit + (size_t)gz * g.wchunks * WSLAB;
-        constexpr int PPC = WB / 16;
-        for (int p = tid; p < nch * PPC; p += RR_NT) {
-            const int c = p / PPC, pp = p - c * PPC, row = pp >> 1;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(src + (size_t)c * WSLAB + pp * 16);
-            *reinterpret_cast<u32x4*>(smem + c * WB + row * 32 + ((((pp & 1) ^ (row >> 3)) & 1) << 4)) = v;
+        constexpr int PPC = WB / 16, WBATCH = 6;
+        // [r6] six 16-byte pieces per thread in flight (as one piece per trip, hipcc waited for each load before the next: six to
+        // twelve serial L2 round trips, 6-9 us of every launch before its first MFMA)
+        for (int p0 = tid; p0 < nch * PPC; p0 += RR_NT * WBATCH) {
+            u32x4 v[WBATCH];
+#pragma unroll
+            for (int j = 0; j < WBATCH; j++) {
+                const int p = min(p0 + j * RR_NT, nch * PPC - 1), c = p / PPC, pp = p - c * PPC;
+                v[j] = *reinterpret_cast<const u32x4*>(src + (size_t)c * WSLAB + pp * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < WBATCH; j++) {
+                const int p = p0 + j * RR_NT, c = p / PPC, pp = p - c * PPC, row = pp >> 1;
+                if (p < nch * PPC) *reinterpret_cast<u32x4*>(smem + c * WB + row * 32 + ((((pp & 1) ^ (row >> 3)) & 1) << 4)) = v[j];
+            }
         }
         for (int kc = tid; kc < nch * KH; kc += RR_NT) {
             const bool fa = kc < ca16 * KH;
@@ -1095,15 +1167,28 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
             const ConvSrc& sr = fa ? g.a : g.b;
             float2 t = make_float2(0.0f, 0.0f);
             if (c < sr.C) t = bn_ab(sr.bn, c);
-            tab_a[kc] = t.x * (PLANAR ? XSP : XS1);
-            tab_b[kc] = t.y * (PLANAR ? XSP : XS1);
+            if (SWP) {
+                const int blk = (kc >> 3) * 16 + (kc & 7);     // (chunk, k-group) block, channel within it
+                tab_a[blk] = t.x * XS1;
+                tab_a[blk + 8] = t.y * XS1;
+            } else {
+                tab_a[kc] = t.x * (PLANAR ? XSP : XS1);
+                tab_b[kc] = t.y * (PLANAR ? XSP : XS1);
+            }
         }
         if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (PLANAR ? XSP : XS1 * WS1);
         if (tid < 32 * BN_WORDS) bnacc[tid] = 0;
-        if (tid < 8) const_cast<float*>(zeros)[tid] = 0.0f;
+        if (tid < 16) const_cast<float*>(zeros)[tid] = 0.0f;
     }
     __syncthreads();
 
+#ifdef AIPT_R_CLOCK
+    if (lane == 0) clk_w[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef AIPT_R_PRIO
+    if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);      // (wave: an SGPR -- a scalar branch)
+    if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
+#endif
     const int hh = H >> 1, hw = W >> 1;
     // Output through buffer descriptors: a store's address is (descriptor, per-lane byte offset, SCALAR byte offset) -- the row /
     // channel-quad part is scalar arithmetic and the lanes that must not store carry an offset past the descriptor's size (the
@@ -1114,14 +1199,15 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
     const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(g.out, 0, (int)(g.d2s ? 4u * (unsigned)(H * W) * 16u : aq * (unsigned)(H * W) * 16u), 0x00020000);
     const __amdgpu_buffer_rsrc_t pool_rs = __builtin_amdgcn_make_buffer_rsrc(g.pool_out ? g.pool_out : g.out, 0, (int)(aq * (unsigned)(hh * hw) * 16u), 0x00020000);
     constexpr unsigned NO_STORE = 0x80000000u;                                           // + any scalar offset: past every descriptor (< 2 GiB, host-checked)
+#ifdef AIPT_R_ABL
+    const bool abl_nostore = (AIPT_R_ABL & 16) != 0;           // (every store gets the out-of-range offset: the instruction stream stays, the traffic goes)
+#else
+    constexpr bool abl_nostore = false;
+#endif
     const int q0 = n0 >> 2;
     typedef unsigned u4s __attribute__((ext_vector_type(4)));
-    for (; it < nitems; it += stride) {
-        const int rb = it / tiles_x, tx = it - rb * tiles_x;
-        const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
-        const int x = X + m;
-        const bool xin = x >= 0 && x < W;
-        f32x16 acc[RR_ROWS], acc1[PLANAR ? RR_ROWS : 1];
+    f32x16 acc[RR_ROWS], acc1[PLANAR ? RR_ROWS : 1];
+    auto acc_init = [&]() {
         if (PLANAR) {
 #pragma unroll
             for (int r = 0; r < RR_ROWS; r++)
@@ -1136,8 +1222,225 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                 for (int r = 0; r < RR_ROWS; r++) { acc[r][4 * j] = bq[0]; acc[r][4 * j + 1] = bq[1]; acc[r][4 * j + 2] = bq[2]; acc[r][4 * j + 3] = bq[3]; }
             }
         }
+    };
+    auto epilogue = [&](const int y0, const int x) {
+        // ---- epilogue.  D (32 x 32): register k of lane l = channel (k & 3) + 8 (k >> 2) + 4 (l >> 5), pixel l & 31: registers
+        // 4 j .. 4 j + 3 are channel quad 2 j + (l >> 5) of this lane's pixel
+        const bool lane_ok = m >= 1 && m <= RR_PX && x < W;
+        float s1[16], s2[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { s1[k] = 0.f; s2[k] = 0.f; }
+#pragma unroll
+        for (int r = 0; r < RR_ROWS; r++) {
+            if (PLANAR) acc[r] = (acc[r] + acc1[PLANAR ? r : 0] * (1.0f / LO_SCALE)) * (1.0f / XSP);
+            else acc[r] = acc[r] * (1.0f / (XS1 * WS1));
+            if (g.out_lrelu) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc[r][k] = fmaxf(acc[r][k], acc[r][k] * SLOPE);
+            }
+            const int y = y0 + r;
+            if (y < H) {                                       // wave-uniform
+#pragma unroll
+                for (int k = 0; k < 16; k++) { s1[k] += acc[r][k]; s2[k] = fmaf(acc[r][k], acc[r][k], s2[k]); }
+                if (g.d2s) {
+                    // upsample + conv as a half-resolution conv (see conv3x3_f16x3): virtual channel 4 p + c is channel c of the child
+                    // (2 y + (p >> 1), 2 x + (p & 1)) of this lane's pixel; register quad j of half gq is parity p = 2 j + gq, its fourth
+                    // value an exact zero (zero weights and bias): one C4 store per parity.  Lane part: child column 2 x + gq;
+                    // scalar part: child row 2 y + j
+                    const unsigned voff = lane_ok && !abl_nostore ? (unsigned)(2 * x + gq) * 16u : NO_STORE;
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
+                                                               out_rs, voff, (unsigned)((2 * y + j) * (2 * W)) * 16u, 0);
+                } else {
+                    const unsigned voff = lane_ok && !abl_nostore ? (unsigned)x * 16u + (gq ? (unsigned)(H * W) * 16u : 0u) : NO_STORE;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((unsigned)(q0 + 2 * j) >= aq) continue;      // (scalar) the whole quad pair lies past the allocation
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
+                                                               out_rs, voff, (unsigned)((q0 + 2 * j) * H + y) * (unsigned)W * 16u, 0);
+                    }
+                }
+            }
+        }
+        if (g.pool_out) {
+            // 2x2 pool of the raw output (see conv3x3_f16x3): rows 2 rp, 2 rp + 1 are registers of this lane, columns x (even: odd
+            // m) and x + 1 are this lane and the next
+#pragma unroll
+            for (int rp = 0; rp < RR_ROWS / 2; rp++) {
+                const int y = y0 + 2 * rp;
+                // max where gamma >= 0, min where gamma < 0, as ONE instruction per pair: med3(a, b, +inf) = max(a, b),
+                // med3(a, b, -inf) = min(a, b) (selecting between a computed max and a computed min cost three)
+                float pv[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const float lim = ((posmask >> k) & 1u) ? INFINITY : -INFINITY;
+                    const float v = __builtin_amdgcn_fmed3f(acc[2 * rp][k], acc[2 * rp + 1][k], lim);
+                    const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
+                    pv[k] = __builtin_amdgcn_fmed3f(v, o, lim);
+                }
+                if (y < H) {
+                    const unsigned voff = ((m & 1) && m < RR_PX && x < W && !abl_nostore) ? (unsigned)(x >> 1) * 16u + (gq ? (unsigned)(hh * hw) * 16u : 0u) : NO_STORE;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((unsigned)(q0 + 2 * j) >= aq) continue;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]}),
+                                                               pool_rs, voff, (unsigned)((q0 + 2 * j) * hh + (y >> 1)) * (unsigned)hw * 16u, 0);
+                    }
+                }
+            }
+        }
+        if (g.stat) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) { s1[k] = lane_ok ? s1[k] : 0.f; s2[k] = lane_ok ? s2[k] : 0.f; }
+            // [r5] committed item by item to the workgroup's fixed-point accumulators (integer adds): the sums do not depend on
+            // which wave of which workgroup ran which item -- the same bits on any number of CUs (aipt_frame_prefetch runs this
+            // kernel on a CU-masked stream with fewer workgroups); measured free against one fp32 running sum per wave
+            const float h1 = halfwave_sum16(s1, m), h2 = halfwave_sum16(s2, m);
+            if (m < 16) {                                      // lanes m < 16 of both halves hold channel (k & 3) + 8 (k >> 2) + 4 gq, k as in halfwave_sum16
+                const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
+                int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
+                if (g.d2s) cl = cl < 16 ? (cl & 3) : 31;       // a channel's four children share its sums (slot 31: the unused virtual channels, all zero)
+                const BnFix fx = bn_fix((double)h1), fq = bn_fix((double)h2);
+                unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
+                atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
+                atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
+            }
+        }
+    };
+    if constexpr (SWP) {
+        // ================= software-pipelined main loop: one instruction stream in issue order (see swp_* above) =================
+        constexpr int PM = W16 ? 2 : 3;                        // MFMAs of a (tap, output row) pair: hi.hi, lo.hi, hi.lo
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        unsigned X[2][8];                                      // split operands of halo rows h (even / odd): [0..3] hi pairs, [4..7] lo pairs
+        unsigned SR[8], SL[8];                                 // the same shifted by one lane: column taps kx = 0 / kx = 2
+        f16x8 FW[2][2];                                        // weight fragments {hi, lo} of the current and the next (tap, row) pair
+        f32x4 cq[4];                                           // BN coefficients of the row being transformed: a[0..3], a[4..7], b[0..3], b[4..7]
+        float tf[4];
+        const float* tp = zeros;
+        if (it < nitems) {
+            // ---- geometry of the item being computed (y0, x, xin), of the next item (n_*), and of the step after this one (s_*)
+            int y0 = 0, x = 0; bool xin = false;
+            int n_y0 = 0; bool n_xin = false;
+            auto item_geom = [&](int item, int& gy0, int& gx, bool& gxin) {
+                const int rb = item / tiles_x, tx = item - rb * tiles_x;
+                gy0 = (rb0 + rb) * RR_ROWS; gx = tx * RR_PX - 1 + m; gxin = gx >= 0 && gx < W;
+            };
+            item_geom(it, y0, x, xin);
+            // one transform instruction: position k = 9 pair + step of halo row `slot`'s 36 (pair p: channels 2 (p & 1), 2 (p & 1) + 1 of quad p >> 1)
+            auto xf_op = [&](auto KC_, auto SLOT_, auto PAR_, const float slope) {
+                constexpr int k = decltype(KC_)::value, slot = decltype(SLOT_)::value, par = decltype(PAR_)::value;
+                constexpr int p = k / 9, kk = k % 9, q = p >> 1, e = (p & 1) * 2;
+                if constexpr (kk == 0) tf[0] = fmaf(cq[q][e], raw[slot][q][e], cq[2 + q][e]);
+                if constexpr (kk == 1) tf[1] = fmaf(cq[q][e + 1], raw[slot][q][e + 1], cq[2 + q][e + 1]);
+                if constexpr (kk == 2) tf[2] = tf[0] * slope;
+                if constexpr (kk == 3) tf[3] = tf[1] * slope;
+                if constexpr (kk == 4) tf[0] = fmaxf(tf[0], tf[2]);
+                if constexpr (kk == 5) tf[1] = fmaxf(tf[1], tf[3]);
+                if constexpr (kk == 6) X[par][p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tf[0], tf[1]));
+                if constexpr (kk == 7) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(X[par][4 + p]) : "v"(X[par][p]), "v"(tf[0]));
+                if constexpr (kk == 8) asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(X[par][4 + p]) : "v"(X[par][p]), "v"(tf[1]));
+            };
+            auto frag_rd = [&](const unsigned char* wbase, const int tap, f16x8 (&dst)[2], const int part) {
+                if (part == 0) dst[0] = *reinterpret_cast<const f16x8*>(wbase + tap * 1024);
+                else dst[1] = *reinterpret_cast<const f16x8*>(wbase + (9 + tap) * 1024);
+            };
+            // ---- pipeline prologue: halo row 0 of the first step transformed and shifted, its first fragments read, row 3 requested
+            {
+                const bool ok = xin && (unsigned)(y0 - 1) < (unsigned)H;
+                tp = ok ? tab_a + gq * 16 : zeros;
+#pragma unroll
+                for (int j = 0; j < 4; j++) cq[j] = *reinterpret_cast<const f32x4*>(tp + 4 * j);
+                const float slope0 = 0 < ca16 ? g.a.slope : g.b.slope;
+                static_for<0, 36>([&](auto K_) { xf_op(K_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, slope0); });
+                if (PF == 6) {                                 // (a ring of six rows: row 0 of the step after this one)
+                    if (++pf_c == nch) {
+                        pf_c = 0;
+                        if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }
+                    }
+                    pf_chunk();
+                }
+                issue(0, PF % 6);
+#pragma unroll
+                for (int j = 0; j < 8; j++) SR[j] = dpp_wave_shr1(X[0][j]);
+                frag_rd(smem + w_rd, swp_tap_of(0), FW[0], 0);
+                frag_rd(smem + w_rd, swp_tap_of(1), FW[1], 0);
+                if (!W16) frag_rd(smem + w_rd, swp_tap_of(0), FW[0], 1);
+            }
+            for (; it < nitems; it += stride) {
+                item_geom(it, y0, x, xin);
+                if (it + stride < nitems) { int nx; item_geom(it + stride, n_y0, nx, n_xin); }
+                else { n_y0 = y0; n_xin = xin; }          // (past the last item: a harmless transform of re-read rows)
+                acc_init();
+                for (int c = 0; c < nch; c++) {
+                    const bool lastc = c + 1 == nch;
+                    const int s_c = lastc ? 0 : c + 1;                               // the step after this one: its chunk,
+                    const int s_y0 = lastc ? n_y0 : y0;                              // first output row,
+                    const bool s_xin = lastc ? n_xin : xin;                          // column mask,
+                    const unsigned char* const wl = smem + c * WB + w_rd;            // this step's weights
+                    const unsigned char* const s_wl = smem + s_c * WB + w_rd;        // and the next step's
+                    const float slope = c < ca16 ? g.a.slope : g.b.slope, s_slope = s_c < ca16 ? g.a.slope : g.b.slope;
+                    static_for<0, 6>([&](auto H_) {
+                        constexpr int h = decltype(H_)::value, n = (h + 1) % 6;      // n: the halo row transformed in this region
+                        constexpr int nky = swp_nky(h), ky0 = swp_ky0(h), NT = 3 * nky, NM = NT * PM;
+                        constexpr int par = h & 1, npar = n & 1, slot = n % PF, hp = (n + PF) % 6;   // hp: the row requested into the slot row n leaves
+                        const bool okn = h == 5 ? (s_xin && (unsigned)(s_y0 - 1) < (unsigned)H) : (xin && (unsigned)(y0 - 1 + n) < (unsigned)H);
+                        const float* const tabn = tab_a + ((h == 5 ? s_c : c) * 2 + gq) * 16;
+                        const float nslope = h == 5 ? s_slope : slope;
+                        static_for<0, NM>([&](auto I_) {
+                            constexpr int i = decltype(I_)::value, t = i / PM, s = i % PM;
+                            constexpr int kx = t / nky, ky = ky0 + t % nky, r = h - ky, G = swp_tr0(h) + t, fs = G & 1;
+                            // ---- the MFMA
+                            const unsigned* bsrc = kx == 0 ? SR : kx == 1 ? X[par] : SL;
+                            const bool lo_b = s == PM - 1;                           // hi.hi, (lo.hi,) hi.lo
+                            const f16x8 fb = __builtin_bit_cast(f16x8, (u4){bsrc[lo_b ? 4 : 0], bsrc[lo_b ? 5 : 1], bsrc[lo_b ? 6 : 2], bsrc[lo_b ? 7 : 3]});
+                            const f16x8 fa = (!W16 && s == 1) ? FW[fs][1] : FW[fs][0];
+                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[r], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // ---- its shadow: weight fragments three MFMAs ahead of their use -- the lo fragment of the next pair (its
+                            // register set last served the pair before this one), the hi fragment of the pair after the next one (into
+                            // the registers this pair's last MFMA has just read) ...
+                            if constexpr (!W16 && s == 0) frag_rd(G + 1 >= 36 ? s_wl : wl, swp_tap_of(G + 1), FW[fs ^ 1], 1);
+                            if constexpr (s == PM - 1) frag_rd(G + 2 >= 36 ? s_wl : wl, swp_tap_of(G + 2), FW[fs], 0);
+                            // ... and this region's share of the stream
+                            static_for<i * SWP_OPS / NM, (i + 1) * SWP_OPS / NM>([&](auto O_) {
+                                constexpr int o = decltype(O_)::value;
+                                if constexpr (o == 0) tp = okn ? tabn : zeros;
+                                else if constexpr (o <= 4) cq[o - 1] = *reinterpret_cast<const f32x4*>(tp + 4 * (o - 1));
+                                else if constexpr (o <= 12) SL[o - 5] = dpp_wave_shl1(X[par][o - 5]);
+                                else if constexpr (o <= 48) xf_op(std::integral_constant<int, o - 13>{}, std::integral_constant<int, slot>{}, std::integral_constant<int, npar>{}, nslope);
+                                else if constexpr (o == 49) {
+                                    // the ring slot is free: request the row four ahead (into the next chunk / item when that wraps)
+                                    if constexpr (hp == 0) {
+                                        if (++pf_c == nch) {
+                                            pf_c = 0;
+                                            if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }   // (past the end: harmless re-reads)
+                                        }
+                                        pf_chunk();
+                                    }
+                                    issue(slot, hp);
+                                }
+                                else if constexpr (o >= 51) SR[o - 51] = dpp_wave_shr1(X[npar][o - 51]);
+                            });
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    });
+                }
+                epilogue(y0, x);
+            }
+        }
+    } else {
+    for (; it < nitems; it += stride) {
+        const int rb = it / tiles_x, tx = it - rb * tiles_x;
+        const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
+        const int x = X + m;
+        const bool xin = x >= 0 && x < W;
+        acc_init();
         for (int c = 0; c < nch; c++) {
             const float slope = c < ca16 ? g.a.slope : g.b.slope;
+#ifdef AIPT_R_ABL
+            const f16x8 abl_w = *reinterpret_cast<const f16x8*>(smem + c * WB + w_rd);
+#endif
             // the chunk's 18 weight fragments and this lane's 16 BN coefficients stay in registers for its six halo rows
             const unsigned char* wl = smem + c * WB + w_rd;
             // (WC; without it they are re-read from LDS where they are used: fewer registers, three waves per SIMD)
@@ -1195,6 +1498,9 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                         xl[p] = split_lo_mix(xh[p], v0, v1);
                     }
                     if (WC) { xh[p] = ok ? xh[p] : 0u; xl[p] = ok ? xl[p] : 0u; }
+#ifdef AIPT_R_ABL
+                    if (AIPT_R_ABL & 8) { xh[p] = __builtin_bit_cast(unsigned, rw[e]); xl[p] = __builtin_bit_cast(unsigned, rw[e + 1]); }
+#endif
                 }
                 // ---- the ring slot is free: fetch PF rows ahead (into the next chunk / the next item when that wraps)
                 if ((h + PF) % (RR_ROWS + 2) == 0) {
@@ -1202,6 +1508,7 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                         pf_c = 0;
                         if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }   // (past the end: harmless re-reads)
                     }
+                    pf_chunk();
                 }
                 issue(h % PF, (h + PF) % (RR_ROWS + 2));
                 // ---- MFMAs of every (output row, tap row) pair this halo row serves
@@ -1220,11 +1527,22 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                     for (int ky = 0; ky < 3; ky++) {
                         const int r = h - ky;
                         if (r < 0 || r >= RR_ROWS) continue;
+#ifdef AIPT_R_ABL   // ablation builds (results wrong by design): 1 no weight-fragment reads, 2 no epilogue, 4 no MFMAs, 8 no transform
+                        const f16x8 fwh = (AIPT_R_ABL & 1) ? abl_w : WC ? wfh[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
+#else
                         const f16x8 fwh = WC ? wfh[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (ky * 3 + kx) * 1024);
+#endif
                         f32x16& lo_acc = PLANAR ? acc1[PLANAR ? r : 0] : acc[r];
+#ifdef AIPT_R_ABL
+                        if (AIPT_R_ABL & 4) { acc[r][(ky * 3 + kx) & 15] += __builtin_bit_cast(float, sh[0] ^ sl[1]) + (float)fwh[1]; continue; }
+#endif
                         acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxh, acc[r], 0, 0, 0);
                         if (!W16) {
+#ifdef AIPT_R_ABL
+                            const f16x8 fwl = (AIPT_R_ABL & 1) ? abl_w : WC ? wfl[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
+#else
                             const f16x8 fwl = WC ? wfl[ky * 3 + kx] : *reinterpret_cast<const f16x8*>(wl + (9 + ky * 3 + kx) * 1024);
+#endif
                             lo_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl, fxh, lo_acc, 0, 0, 0);
                         }
                         lo_acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh, fxl, lo_acc, 0, 0, 0);
@@ -1232,92 +1550,28 @@ __global__ __launch_bounds__(NWV * 64, PLANAR ? 2 : 3) void conv3x3_f16x3r(const
                 }
             }
         }
-
-        // ---- epilogue.  D (32 x 32): register k of lane l = channel (k & 3) + 8 (k >> 2) + 4 (l >> 5), pixel l & 31: registers
-        // 4 j .. 4 j + 3 are channel quad 2 j + (l >> 5) of this lane's pixel
-        const bool lane_ok = m >= 1 && m <= RR_PX && x < W;
-        float s1[16], s2[16];
+#ifdef AIPT_R_ABL
+        if (AIPT_R_ABL & 2) {                                  // one store so that the accumulators stay live
+            float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { s1[k] = 0.f; s2[k] = 0.f; }
+            for (int r = 0; r < RR_ROWS; r++)
 #pragma unroll
-        for (int r = 0; r < RR_ROWS; r++) {
-            if (PLANAR) acc[r] = (acc[r] + acc1[PLANAR ? r : 0] * (1.0f / LO_SCALE)) * (1.0f / XSP);
-            else acc[r] = acc[r] * (1.0f / (XS1 * WS1));
-            if (g.out_lrelu) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) acc[r][k] = fmaxf(acc[r][k], acc[r][k] * SLOPE);
-            }
-            const int y = y0 + r;
-            if (y < H) {                                       // wave-uniform
-#pragma unroll
-                for (int k = 0; k < 16; k++) { s1[k] += acc[r][k]; s2[k] = fmaf(acc[r][k], acc[r][k], s2[k]); }
-                if (g.d2s) {
-                    // upsample + conv as a half-resolution conv (see conv3x3_f16x3): virtual channel 4 p + c is channel c of the child
-                    // (2 y + (p >> 1), 2 x + (p & 1)) of this lane's pixel; register quad j of half gq is parity p = 2 j + gq, its fourth
-                    // value an exact zero (zero weights and bias): one C4 store per parity.  Lane part: child column 2 x + gq;
-                    // scalar part: child row 2 y + j
-                    const unsigned voff = lane_ok ? (unsigned)(2 * x + gq) * 16u : NO_STORE;
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
-                                                               out_rs, voff, (unsigned)((2 * y + j) * (2 * W)) * 16u, 0);
-                } else {
-                    const unsigned voff = lane_ok ? (unsigned)x * 16u + (gq ? (unsigned)(H * W) * 16u : 0u) : NO_STORE;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if ((unsigned)(q0 + 2 * j) >= aq) continue;      // (scalar) the whole quad pair lies past the allocation
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{acc[r][4 * j], acc[r][4 * j + 1], acc[r][4 * j + 2], acc[r][4 * j + 3]}),
-                                                               out_rs, voff, (unsigned)((q0 + 2 * j) * H + y) * (unsigned)W * 16u, 0);
-                    }
-                }
-            }
+                for (int k = 0; k < 16; k++) t += acc[r][k];
+            if (t == 123.456f) g.out[lane] = t;
+            continue;
         }
-        if (g.pool_out) {
-            // 2x2 pool of the raw output (see conv3x3_f16x3): rows 2 rp, 2 rp + 1 are registers of this lane, columns x (even: odd
-            // m) and x + 1 are this lane and the next
-#pragma unroll
-            for (int rp = 0; rp < RR_ROWS / 2; rp++) {
-                const int y = y0 + 2 * rp;
-                // max where gamma >= 0, min where gamma < 0, as ONE instruction per pair: med3(a, b, +inf) = max(a, b),
-                // med3(a, b, -inf) = min(a, b) (selecting between a computed max and a computed min cost three)
-                float pv[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const float lim = ((posmask >> k) & 1u) ? INFINITY : -INFINITY;
-                    const float v = __builtin_amdgcn_fmed3f(acc[2 * rp][k], acc[2 * rp + 1][k], lim);
-                    const float o = __builtin_bit_cast(float, dpp_wave_shl1(__builtin_bit_cast(unsigned, v)));
-                    pv[k] = __builtin_amdgcn_fmed3f(v, o, lim);
-                }
-                if (y < H) {
-                    const unsigned voff = ((m & 1) && m < RR_PX && x < W) ? (unsigned)(x >> 1) * 16u + (gq ? (unsigned)(hh * hw) * 16u : 0u) : NO_STORE;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if ((unsigned)(q0 + 2 * j) >= aq) continue;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, f32x4{pv[4 * j], pv[4 * j + 1], pv[4 * j + 2], pv[4 * j + 3]}),
-                                                               pool_rs, voff, (unsigned)((q0 + 2 * j) * hh + (y >> 1)) * (unsigned)hw * 16u, 0);
-                    }
-                }
-            }
-        }
-        if (g.stat) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) { s1[k] = lane_ok ? s1[k] : 0.f; s2[k] = lane_ok ? s2[k] : 0.f; }
-            // [r5] committed item by item to the workgroup's fixed-point accumulators (integer adds): the sums do not depend on
-            // which wave of which workgroup ran which item -- the same bits on any number of CUs (aipt_frame_prefetch runs this
-            // kernel on a CU-masked stream with fewer workgroups); measured free against one fp32 running sum per wave
-            const float h1 = halfwave_sum16(s1, m), h2 = halfwave_sum16(s2, m);
-            if (m < 16) {                                      // lanes m < 16 of both halves hold channel (k & 3) + 8 (k >> 2) + 4 gq, k as in halfwave_sum16
-                const int k = 8 * (m & 1) + 4 * ((m >> 1) & 1) + 2 * ((m >> 2) & 1) + ((m >> 3) & 1);
-                int cl = (k & 3) + 8 * (k >> 2) + 4 * gq;
-                if (g.d2s) cl = cl < 16 ? (cl & 3) : 31;       // a channel's four children share its sums (slot 31: the unused virtual channels, all zero)
-                const BnFix fx = bn_fix((double)h1), fq = bn_fix((double)h2);
-                unsigned long long* acc4 = reinterpret_cast<unsigned long long*>(bnacc + cl * BN_WORDS);
-                atomicAdd(acc4, (unsigned long long)fx.i); atomicAdd(acc4 + 1, (unsigned long long)fx.f);
-                atomicAdd(acc4 + 2, (unsigned long long)fq.i); atomicAdd(acc4 + 3, (unsigned long long)fq.f);
-            }
-        }
+#endif
+        epilogue(y0, x);
+    }
     }
 
+#ifdef AIPT_R_CLOCK
+    if (lane == 0) {
+        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+        clk_w[2] = r1;
+        if (blockIdx.x == 8 && tid == 0) { g_rclk[g.ablate & 31][6] = __builtin_amdgcn_s_memtime() - clk_t0; g_rclk[g.ablate & 31][7] = r1 - clk_r0; }
+    }
+#endif
     // ---- BN sums of the workgroup -> the layer's table
     if (g.stat) {
         __syncthreads();
@@ -1841,6 +2095,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.stat = stat; gh.sc = DenoiseState::STAT_SC;
         gh.d2s = L.cout;
         gh.pool_out = nullptr; gh.pool_gamma = nullptr; gh.ablate = 0;
+#ifdef AIPT_R_CLOCK
+        gh.ablate = li;
+#endif
         const int r_wpg = s->run_cus / 8;
         if ((long long)gh.H * gh.W >= s->opt_r_minpix && gh.nchunks <= RR_MAXCH && r_wpg >= 1 && !(gh.H & 1) && !(gh.W & 1) && L.d_wsplit1_d2s[0] &&
             (long long)H * W * 16 < (1ll << 31) &&
@@ -1849,8 +2106,8 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             gh.wsplit = L.d_wsplit1_d2s[w16_mode(s) ? 1 : 0]; gh.bias = L.d_bias32_d2s4;
             gh.cout = 16;
             gh.tiles_x = (gh.W + RR_PX - 1) / RR_PX; gh.tiles_y = (gh.H + 3) / 4; gh.groups = 1;
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<false,12,3,false,4,false>");
-            hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(8u * (unsigned)r_wpg), dim3(768), convr_lds_bytes(gh.nchunks, false), s->cur, gh);
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<false,%d,%d,false,4,false>", R_NWV, R_PF);
+            hipLaunchKernelGGL((conv3x3_f16x3r<false, R_NWV, R_PF, false>), dim3(8u * (unsigned)r_wpg), dim3(R_NWV * 64), convr_lds_bytes(gh.nchunks, false), s->cur, gh);
         } else {
             const dim3 grid((gh.W + 31) / 32, (gh.H + 7) / 8, 1);
             gh.tiles_x = grid.x; gh.tiles_y = grid.y; gh.groups = 1;
@@ -1893,6 +2150,9 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         gh.d2s = 0;
         gh.pool_out = pool_dst ? pool_dst->p : nullptr; gh.pool_gamma = L.d_gamma;
         gh.ablate = 0;
+#ifdef AIPT_R_CLOCK
+        gh.ablate = li;
+#endif
 #ifdef AIPT_CONV_ABLATE
         static const int ablate_env = getenv("AIPT_CONV_ABLATE") ? (int)strtol(getenv("AIPT_CONV_ABLATE"), nullptr, 0) : 0;
         gh.ablate = ablate_env;
@@ -1912,12 +2172,12 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
             const unsigned pgrid = 8u * (unsigned)r_wpg * (unsigned)r_groups;
             const size_t lds = convr_lds_bytes(gh.nchunks, w16);
             // the name rocprofv3 reports for the instantiation, without blanks (bench.py matches profiles/ on it)
-            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%s,%s>", w16 ? "true" : "false",
-                     gh.a.planar ? "8,3,false,4" : "12,3,false,4", gh.a.planar ? "true" : "false");
+            snprintf(s->kname[li], sizeof(s->kname[li]), "conv3x3_f16x3r<%s,%d,%d,false,4,%s>", w16 ? "true" : "false",
+                     gh.a.planar ? 8 : R_NWV, gh.a.planar ? 3 : R_PF, gh.a.planar ? "true" : "false");
             if (gh.a.planar && w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
             else if (gh.a.planar) hipLaunchKernelGGL((conv3x3_f16x3r<false, 8, 3, false, 4, true>), dim3(pgrid), dim3(512), lds, s->cur, gh);
-            else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
-            else hipLaunchKernelGGL((conv3x3_f16x3r<false, 12, 3, false>), dim3(pgrid), dim3(768), lds, s->cur, gh);
+            else if (w16) hipLaunchKernelGGL((conv3x3_f16x3r<true, R_NWV, R_PF, false>), dim3(pgrid), dim3(R_NWV * 64), lds, s->cur, gh);
+            else hipLaunchKernelGGL((conv3x3_f16x3r<false, R_NWV, R_PF, false>), dim3(pgrid), dim3(R_NWV * 64), lds, s->cur, gh);
         } else {
             // LDS-tiled kernel.  Tile rows = waves per workgroup: 8, or 4 on the levels below opt_f16_minpix (too few 8 x 32 tiles
             // for 256 CUs); the planar input always on 8-row tiles
@@ -1958,6 +2218,41 @@ static int run_conv(aipt_ctx* ctx, DenoiseState* s, int li, const Tensor& A, int
         }
     }
     if (prof) AIPT_HIP(ctx, hipEventRecord(pev[1], s->cur));
+#ifdef AIPT_R_CLOCK
+    {
+        static unsigned long long h[32][8];
+        static std::vector<unsigned long long> hw(32 * 4096 * 4);
+        static int calls = 0;
+        auto reset = [&]() {
+            for (auto& r : h) { r[0] = ~0ull; r[1] = 0; r[2] = ~0ull; r[3] = 0; r[4] = 0; r[5] = 0; r[6] = 0; r[7] = 1; }
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rclk), h, sizeof(h));
+            std::fill(hw.begin(), hw.end(), 0ull);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rclk_w), hw.data(), hw.size() * 8);
+        };
+        if (calls == 0) { (void)hipDeviceSynchronize(); reset(); }
+        if (li == NLAYERS - 1 && ++calls % 16 == 12) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rclk), sizeof(h));
+            (void)hipMemcpyFromSymbol(hw.data(), HIP_SYMBOL(g_rclk_w), hw.size() * 8);
+            unsigned long long prev_end = 0;
+            for (int l = 0; l < NLAYERS; l++) {
+                for (int w = 0; w < 4096; w++) {
+                    const unsigned long long* q = &hw[((size_t)l * 4096 + w) * 4];
+                    if (!q[0] || !q[2]) continue;
+                    h[l][0] = std::min(h[l][0], q[0]); h[l][1] = std::max(h[l][1], q[0]);
+                    h[l][2] = std::min(h[l][2], q[2]); h[l][3] = std::max(h[l][3], q[2]);
+                    h[l][4] = std::max(h[l][4], q[1]);
+                }
+                if (h[l][1] == 0) continue;
+                fprintf(stderr, "rclk layer %2d %-44s gap %6.2f  ramp %5.2f  prologue %5.2f  first-end %6.2f  last-end %6.2f us | wave: %.3f GHz\n", l, s->kname[l],
+                        prev_end ? ((double)h[l][0] - (double)prev_end) * 0.01 : 0.0, (double)(h[l][1] - h[l][0]) * 0.01, (double)(h[l][4] - h[l][0]) * 0.01,
+                        (double)(h[l][2] - h[l][0]) * 0.01, (double)(h[l][3] - h[l][0]) * 0.01, (double)h[l][6] / (double)h[l][7] * 0.1);
+                prev_end = h[l][3];
+            }
+            reset();
+        } else if (li == NLAYERS - 1) { (void)hipDeviceSynchronize(); reset(); }
+    }
+#endif
     // how consumers normalise dst: batch statistics from the sums this launch accumulates, or the running-statistics affine
     if (batch) dst.bn = BnRef{nullptr, stat, L.d_gamma, L.d_beta, DenoiseState::STAT_SC, 1.0 / ((double)H * (double)W)};
     else dst.bn = BnRef{L.d_ab_running, nullptr, nullptr, nullptr, 0, 0.0};

@@ -21,6 +21,11 @@ Round 5 -- cases at the sizes where the register-staged kernel `conv3x3_f16x3r` 
 include/aiptd.h AIPT_DN_OPT_R_MINPIX): one 384x640 frame stored in full (level 0 on that kernel) and one 736x1280 frame -- the
 benchmark size, levels 0 and 1 on it -- stored as 65 536 strided samples + per-channel fp64 mean / mean-square of the output.
 
+Round 6 -- `b_carry_384x640`: two frames with the hidden state carried (model(x0, 0), model(x1, 1)): the reset cases above multiply
+the hidden half of every `layer2.0` input (recurrent_autoencoder_model.py:64-67 `torch.cat((out1, self.hidden))`) by zeros, so the
+register-staged kernel's hidden-channel weights met reference output only at <= 96x160 through the LDS-tiled kernel.  Stored as
+131 072 strided samples over both frames + per-frame per-channel fp64 moments.
+
 Usage: python tests/golden/gen_denoise_goldens.py [case-name ...]      (no names: all cases)
 """
 import os
@@ -48,8 +53,9 @@ CASES = [
     ("r_reset_96x160", 96, 160, 566,  1, "running", 1),
     ("b_reset_384x640", 384, 640, 567, 2, "batch",  1),
     ("b_reset_736x1280", 736, 1280, 568, 3, "batch", 1),      # stored as samples + moments (SAMPLED below)
+    ("b_carry_384x640", 384, 640, 569, 4, "batch",  2),       # [r6] hidden CARRIED into frame 1 at a size conv3x3_f16x3r runs
 ]
-SAMPLED = {"b_reset_736x1280": 65536}
+SAMPLED = {"b_reset_736x1280": 65536, "b_carry_384x640": 131072}
 
 
 def hidden_summary(h):

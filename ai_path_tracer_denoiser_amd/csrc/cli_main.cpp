@@ -189,9 +189,10 @@ bool write_hdr(const std::string& path, const float* base, size_t plane, int str
     bool ok = true;
     for (int y = 0; y < h && ok; y++) {
         for (int x = 0; x < w; x++) {
-            // non-finite components (a degraded, unclamped frame) are written as the largest float: frexp of inf has no exponent
-            // and a NaN or out-of-range mantissa cast to unsigned char is undefined
-            auto fin = [](float v) { return v != v ? 0.0f : std::fmin(v, FLT_MAX); };
+            // non-finite or huge components (a degraded, unclamped frame) are written as the largest RGBE value, 255/256 x 2^127: frexp
+            // of inf has no exponent, a NaN or out-of-range mantissa cast to unsigned char is undefined, and from 2^127 on the
+            // exponent byte e + 128 would wrap to 0 (a saturated pixel decoding as black); NaN and negatives (-inf) are 0
+            auto fin = [](float v) { return !(v > 0.0f) ? 0.0f : std::fmin(v, 0x1.fep+126f); };
             const float r = fin(base[(size_t)y * stride + x]), g = fin(base[plane + (size_t)y * stride + x]), b = fin(base[2 * plane + (size_t)y * stride + x]);
             const float m = std::fmax(r, std::fmax(g, b));
             unsigned char* o = &row[(size_t)x * 4];

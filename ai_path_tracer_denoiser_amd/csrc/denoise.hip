@@ -696,6 +696,12 @@ __global__ __launch_bounds__(NWV * KYS * 64, KYS == 3 ? 3 : NWV == 8 ? 4 : 2) vo
             f32x4 v;
 #pragma unroll
             for (int t = 0; t < 4; t++) v[t] = fmaxf(x[t], xs[t]);        // LeakyReLU for 0 < slope <= 1
+            if (PLANAR) {
+                // the network input in the caller's units, times 2^-4: saturates at +-65 504 (|x| = 1 048 064) exactly like the
+                // register-staged kernel's planar conv, so that a frame means the same whichever kernel its size selects
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = __builtin_amdgcn_fmed3f(v[t], -65504.0f, 65504.0f);
+            }
             // hi = fp16(v) rounded toward zero (any fp16 near v works: lo carries the exact remainder, scaled by 2^11)
             const f16x2 h01 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[0], v[1]));
             const f16x2 h23 = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(v[2], v[3]));
@@ -964,12 +970,9 @@ __device__ unsigned long long g_rclk_w[32][4096][4];       // per wave: start, a
 #ifndef AIPT_R_WAVES
 #define AIPT_R_WAVES 12                                       // waves per workgroup of the C4-input instantiations (A/B builds: 8)
 #endif
-#ifndef AIPT_R_PF
-#define AIPT_R_PF 3                                           // halo rows of load lookahead (the register ring) of the C4-input instantiations
-#endif
-constexpr int R_NWV = AIPT_R_WAVES, R_PF = AIPT_R_PF;
+constexpr int R_NWV = AIPT_R_WAVES, R_PF = 3;
 static inline size_t convr_lds_bytes(int nchunks, bool w16) {
-    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * BN_WORDS * 8 + 64;
+    return (size_t)nchunks * (w16 ? WSLAB / 2 : WSLAB) + (size_t)nchunks * KH * 8 + 32 * 4 + 32 * BN_WORDS * 8 + 32;
 }
 
 // lo half of the split: the fp16 roundings of v0 - hi.lo and v1 - hi.hi, packed, in two mixed-precision FMAs (instead of two
@@ -981,7 +984,8 @@ __device__ __forceinline__ unsigned split_lo_mix(unsigned hi, float v0, float v1
     return d;
 }
 // the same for the two-accumulator arithmetic of the planar input: the fp16 roundings of (v - hi) * 2^11, from vs = v * 2^11 and
-// nscale = -2^11 (exact in fp32: hi is v rounded toward zero to 11 bits, the remainder has at most 13)
+// nscale = -2^11 (exact in fp32: hi is v rounded to 11 bits -- to nearest in the planar stash, so the remainder may be negative --
+// and the remainder has at most 13)
 __device__ __forceinline__ unsigned split_lo_mix_scaled(unsigned hi, float v0s, float v1s, float nscale) {
     unsigned d;
     asm("v_fma_mixlo_f16 %0, %1, %3, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hi), "v"(v0s), "v"(nscale));
@@ -1010,33 +1014,6 @@ __device__ __forceinline__ float halfwave_sum16(const float (&s)[16], int m) {
     return a1;
 }
 
-// ---- the software-pipelined main loop of conv3x3_f16x3r [r6] (tools/ubench/mfma_fill.hip, profiles/r06_ubench_mfma_fill.txt)
-// Measured in CYCLES: one wave hides <= 5 single-issue instructions behind every v_mfma_f32_32x32x16_f16 (33-37 cycles per MFMA
-// for 0-5 fillers BETWEEN consecutive MFMAs, three waves per SIMD: 32.3-33.7), while the same instructions in bursts between
-// clusters of MFMAs -- what hipcc makes of the row-by-row source: 45 VALU, then MFMAs with a `ds_read; s_waitcnt lgkmcnt(0)` before
-// each -- cost 39-40 cycles per MFMA at 4-5 fillers with three waves and 53-57 with one.  "VALU time adds to MFMA time" (DESIGN
-// rounds 3-5) was an artefact of measuring MFMAs-THEN-VALU in one in-order wave, in nanoseconds across bodies that clock differently.
-// So the chunk body is written as ONE instruction stream in issue order: after every MFMA of halo row h a few instructions of
-//   * the transform of row h + 1 (BN affine, LeakyReLU, fp16 hi/lo split: 36), its BN coefficients (4 LDS reads) and its wave_shr
-//     column shift (8 DPP moves), this row's wave_shl shift (8), the global loads of the row four ahead (2), and
-//   * the weight fragments of the NEXT (tap, output row) pair (2 LDS reads into the other of two register sets),
-// pinned by a __builtin_amdgcn_sched_barrier(0) on either side (hipcc then only allocates registers and places s_waitcnt / s_nop).
-// Same MFMAs on the same operands in the same order as the row-by-row loop: the same bits.
-template <int B, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
-}
-constexpr int swp_nky(int h) { return (h == 0 || h == 5) ? 1 : (h == 1 || h == 4) ? 2 : 3; }   // tap rows halo row h of a 4-row item serves
-constexpr int swp_ky0(int h) { return h <= 3 ? 0 : h - 3; }                                    // the first of them (output row r = h - ky)
-constexpr int swp_tr0(int h) { int s = 0; for (int k = 0; k < h; k++) s += 3 * swp_nky(k); return s; }   // (tap, row) pairs before row h
-constexpr int swp_row_of(int G) { G %= 36; int h = 0; while (G >= 3 * swp_nky(h)) { G -= 3 * swp_nky(h); h++; } return h; }   // halo row of a step's pair G
-constexpr int swp_tap_of(int G) {                                                             // its tap ky * 3 + kx
-    G %= 36;
-    const int h = swp_row_of(G), t = G - swp_tr0(h), nky = swp_nky(h);
-    return (swp_ky0(h) + t % nky) * 3 + t / nky;
-}
-constexpr int SWP_OPS = 59;        // stream positions of a row region: 0 select, 1-4 coefficients, 5-12 shl, 13-48 transform, 49-50 loads, 51-58 shr
-
 // RR_ROWS = output rows of an item: 4 on the levels with many items; 2 on the small levels (twice the items, half the serial
 // chain of steps per item: those launches last as long as one wave's item).
 // PLANAR: source a is the planar network input [C][h][w], C <= 16 (one chunk): eight 4-byte loads per lane and halo row instead of
@@ -1053,18 +1030,11 @@ __global__ __launch_bounds__(NWV * 64, (PLANAR || NWV <= 8) ? 2 : 3) void conv3x
     constexpr int WB = W16 ? WSLAB / 2 : WSLAB;                // LDS bytes of a chunk's weights
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), m = lane & 31, gq = lane >> 5;   // (wave: an SGPR, so is everything derived from it)
     const int nch = g.nchunks, ca16 = g.ca16, H = g.H, W = g.W, up = g.a.up;
-#ifdef AIPT_R_SWP
-    constexpr bool SWP = !PLANAR && !WC && RR_ROWS == 4 && (PF == 3 || PF == 6);   // A/B builds: the software-pipelined main loop (see swp_* above)
-#else
-    constexpr bool SWP = false;                                // the row-by-row main loop: equally fast, 26 registers fewer (tools/experiments/README.md, round 6)
-#endif
-    // BN coefficient table.  Row-by-row loop: a[nch][16], b[nch][16].  SWP: one 64-byte block {a[8], b[8]} per (chunk, k-group), so
-    // that ONE address select (block or the zero block) serves a row's four 16-byte reads
     float* tab_a = reinterpret_cast<float*>(smem + nch * WB);
     float* tab_b = tab_a + nch * KH;
     float* bias_s = tab_b + nch * KH;                          // [32], times the operand scaling (2^4 2^7 = 2^11, or 2^-4 with PLANAR): the accumulators start from it
     long long* bnacc = reinterpret_cast<long long*>(bias_s + 32);   // [32][BN_WORDS]
-    const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [16]: the BN coefficients of out-of-image pixels
+    const float* zeros = reinterpret_cast<const float*>(bnacc + 32 * BN_WORDS);  // [8]: the BN coefficients of out-of-image pixels
 
 #ifdef AIPT_R_CLOCK
     // debug builds: the shader clock this launch ran at (s_memtime follows DVFS, s_memrealtime is 100 MHz), printed by one wave
@@ -1167,27 +1137,17 @@ __global__ __launch_bounds__(NWV * 64, (PLANAR || NWV <= 8) ? 2 : 3) void conv3x
             const ConvSrc& sr = fa ? g.a : g.b;
             float2 t = make_float2(0.0f, 0.0f);
             if (c < sr.C) t = bn_ab(sr.bn, c);
-            if (SWP) {
-                const int blk = (kc >> 3) * 16 + (kc & 7);     // (chunk, k-group) block, channel within it
-                tab_a[blk] = t.x * XS1;
-                tab_a[blk + 8] = t.y * XS1;
-            } else {
-                tab_a[kc] = t.x * (PLANAR ? XSP : XS1);
-                tab_b[kc] = t.y * (PLANAR ? XSP : XS1);
-            }
+            tab_a[kc] = t.x * (PLANAR ? XSP : XS1);
+            tab_b[kc] = t.y * (PLANAR ? XSP : XS1);
         }
         if (tid < 32) bias_s[tid] = g.bias[n0 + tid] * (PLANAR ? XSP : XS1 * WS1);
         if (tid < 32 * BN_WORDS) bnacc[tid] = 0;
-        if (tid < 16) const_cast<float*>(zeros)[tid] = 0.0f;
+        if (tid < 8) const_cast<float*>(zeros)[tid] = 0.0f;
     }
     __syncthreads();
 
 #ifdef AIPT_R_CLOCK
     if (lane == 0) clk_w[1] = __builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef AIPT_R_PRIO
-    if ((wave >> 2) == 1) __builtin_amdgcn_s_setprio(1);      // (wave: an SGPR -- a scalar branch)
-    if ((wave >> 2) == 2) __builtin_amdgcn_s_setprio(2);
 #endif
     const int hh = H >> 1, hw = W >> 1;
     // Output through buffer descriptors: a store's address is (descriptor, per-lane byte offset, SCALAR byte offset) -- the row /
@@ -1308,128 +1268,6 @@ __global__ __launch_bounds__(NWV * 64, (PLANAR || NWV <= 8) ? 2 : 3) void conv3x
             }
         }
     };
-    if constexpr (SWP) {
-        // ================= software-pipelined main loop: one instruction stream in issue order (see swp_* above) =================
-        constexpr int PM = W16 ? 2 : 3;                        // MFMAs of a (tap, output row) pair: hi.hi, lo.hi, hi.lo
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        unsigned X[2][8];                                      // split operands of halo rows h (even / odd): [0..3] hi pairs, [4..7] lo pairs
-        unsigned SR[8], SL[8];                                 // the same shifted by one lane: column taps kx = 0 / kx = 2
-        f16x8 FW[2][2];                                        // weight fragments {hi, lo} of the current and the next (tap, row) pair
-        f32x4 cq[4];                                           // BN coefficients of the row being transformed: a[0..3], a[4..7], b[0..3], b[4..7]
-        float tf[4];
-        const float* tp = zeros;
-        if (it < nitems) {
-            // ---- geometry of the item being computed (y0, x, xin), of the next item (n_*), and of the step after this one (s_*)
-            int y0 = 0, x = 0; bool xin = false;
-            int n_y0 = 0; bool n_xin = false;
-            auto item_geom = [&](int item, int& gy0, int& gx, bool& gxin) {
-                const int rb = item / tiles_x, tx = item - rb * tiles_x;
-                gy0 = (rb0 + rb) * RR_ROWS; gx = tx * RR_PX - 1 + m; gxin = gx >= 0 && gx < W;
-            };
-            item_geom(it, y0, x, xin);
-            // one transform instruction: position k = 9 pair + step of halo row `slot`'s 36 (pair p: channels 2 (p & 1), 2 (p & 1) + 1 of quad p >> 1)
-            auto xf_op = [&](auto KC_, auto SLOT_, auto PAR_, const float slope) {
-                constexpr int k = decltype(KC_)::value, slot = decltype(SLOT_)::value, par = decltype(PAR_)::value;
-                constexpr int p = k / 9, kk = k % 9, q = p >> 1, e = (p & 1) * 2;
-                if constexpr (kk == 0) tf[0] = fmaf(cq[q][e], raw[slot][q][e], cq[2 + q][e]);
-                if constexpr (kk == 1) tf[1] = fmaf(cq[q][e + 1], raw[slot][q][e + 1], cq[2 + q][e + 1]);
-                if constexpr (kk == 2) tf[2] = tf[0] * slope;
-                if constexpr (kk == 3) tf[3] = tf[1] * slope;
-                if constexpr (kk == 4) tf[0] = fmaxf(tf[0], tf[2]);
-                if constexpr (kk == 5) tf[1] = fmaxf(tf[1], tf[3]);
-                if constexpr (kk == 6) X[par][p] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(tf[0], tf[1]));
-                if constexpr (kk == 7) asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(X[par][4 + p]) : "v"(X[par][p]), "v"(tf[0]));
-                if constexpr (kk == 8) asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(X[par][4 + p]) : "v"(X[par][p]), "v"(tf[1]));
-            };
-            auto frag_rd = [&](const unsigned char* wbase, const int tap, f16x8 (&dst)[2], const int part) {
-                if (part == 0) dst[0] = *reinterpret_cast<const f16x8*>(wbase + tap * 1024);
-                else dst[1] = *reinterpret_cast<const f16x8*>(wbase + (9 + tap) * 1024);
-            };
-            // ---- pipeline prologue: halo row 0 of the first step transformed and shifted, its first fragments read, row 3 requested
-            {
-                const bool ok = xin && (unsigned)(y0 - 1) < (unsigned)H;
-                tp = ok ? tab_a + gq * 16 : zeros;
-#pragma unroll
-                for (int j = 0; j < 4; j++) cq[j] = *reinterpret_cast<const f32x4*>(tp + 4 * j);
-                const float slope0 = 0 < ca16 ? g.a.slope : g.b.slope;
-                static_for<0, 36>([&](auto K_) { xf_op(K_, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, slope0); });
-                if (PF == 6) {                                 // (a ring of six rows: row 0 of the step after this one)
-                    if (++pf_c == nch) {
-                        pf_c = 0;
-                        if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }
-                    }
-                    pf_chunk();
-                }
-                issue(0, PF % 6);
-#pragma unroll
-                for (int j = 0; j < 8; j++) SR[j] = dpp_wave_shr1(X[0][j]);
-                frag_rd(smem + w_rd, swp_tap_of(0), FW[0], 0);
-                frag_rd(smem + w_rd, swp_tap_of(1), FW[1], 0);
-                if (!W16) frag_rd(smem + w_rd, swp_tap_of(0), FW[0], 1);
-            }
-            for (; it < nitems; it += stride) {
-                item_geom(it, y0, x, xin);
-                if (it + stride < nitems) { int nx; item_geom(it + stride, n_y0, nx, n_xin); }
-                else { n_y0 = y0; n_xin = xin; }          // (past the last item: a harmless transform of re-read rows)
-                acc_init();
-                for (int c = 0; c < nch; c++) {
-                    const bool lastc = c + 1 == nch;
-                    const int s_c = lastc ? 0 : c + 1;                               // the step after this one: its chunk,
-                    const int s_y0 = lastc ? n_y0 : y0;                              // first output row,
-                    const bool s_xin = lastc ? n_xin : xin;                          // column mask,
-                    const unsigned char* const wl = smem + c * WB + w_rd;            // this step's weights
-                    const unsigned char* const s_wl = smem + s_c * WB + w_rd;        // and the next step's
-                    const float slope = c < ca16 ? g.a.slope : g.b.slope, s_slope = s_c < ca16 ? g.a.slope : g.b.slope;
-                    static_for<0, 6>([&](auto H_) {
-                        constexpr int h = decltype(H_)::value, n = (h + 1) % 6;      // n: the halo row transformed in this region
-                        constexpr int nky = swp_nky(h), ky0 = swp_ky0(h), NT = 3 * nky, NM = NT * PM;
-                        constexpr int par = h & 1, npar = n & 1, slot = n % PF, hp = (n + PF) % 6;   // hp: the row requested into the slot row n leaves
-                        const bool okn = h == 5 ? (s_xin && (unsigned)(s_y0 - 1) < (unsigned)H) : (xin && (unsigned)(y0 - 1 + n) < (unsigned)H);
-                        const float* const tabn = tab_a + ((h == 5 ? s_c : c) * 2 + gq) * 16;
-                        const float nslope = h == 5 ? s_slope : slope;
-                        static_for<0, NM>([&](auto I_) {
-                            constexpr int i = decltype(I_)::value, t = i / PM, s = i % PM;
-                            constexpr int kx = t / nky, ky = ky0 + t % nky, r = h - ky, G = swp_tr0(h) + t, fs = G & 1;
-                            // ---- the MFMA
-                            const unsigned* bsrc = kx == 0 ? SR : kx == 1 ? X[par] : SL;
-                            const bool lo_b = s == PM - 1;                           // hi.hi, (lo.hi,) hi.lo
-                            const f16x8 fb = __builtin_bit_cast(f16x8, (u4){bsrc[lo_b ? 4 : 0], bsrc[lo_b ? 5 : 1], bsrc[lo_b ? 6 : 2], bsrc[lo_b ? 7 : 3]});
-                            const f16x8 fa = (!W16 && s == 1) ? FW[fs][1] : FW[fs][0];
-                            acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[r], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            // ---- its shadow: weight fragments three MFMAs ahead of their use -- the lo fragment of the next pair (its
-                            // register set last served the pair before this one), the hi fragment of the pair after the next one (into
-                            // the registers this pair's last MFMA has just read) ...
-                            if constexpr (!W16 && s == 0) frag_rd(G + 1 >= 36 ? s_wl : wl, swp_tap_of(G + 1), FW[fs ^ 1], 1);
-                            if constexpr (s == PM - 1) frag_rd(G + 2 >= 36 ? s_wl : wl, swp_tap_of(G + 2), FW[fs], 0);
-                            // ... and this region's share of the stream
-                            static_for<i * SWP_OPS / NM, (i + 1) * SWP_OPS / NM>([&](auto O_) {
-                                constexpr int o = decltype(O_)::value;
-                                if constexpr (o == 0) tp = okn ? tabn : zeros;
-                                else if constexpr (o <= 4) cq[o - 1] = *reinterpret_cast<const f32x4*>(tp + 4 * (o - 1));
-                                else if constexpr (o <= 12) SL[o - 5] = dpp_wave_shl1(X[par][o - 5]);
-                                else if constexpr (o <= 48) xf_op(std::integral_constant<int, o - 13>{}, std::integral_constant<int, slot>{}, std::integral_constant<int, npar>{}, nslope);
-                                else if constexpr (o == 49) {
-                                    // the ring slot is free: request the row four ahead (into the next chunk / item when that wraps)
-                                    if constexpr (hp == 0) {
-                                        if (++pf_c == nch) {
-                                            pf_c = 0;
-                                            if (pf_it + stride < nitems) { pf_it += stride; pf_item(pf_it); }   // (past the end: harmless re-reads)
-                                        }
-                                        pf_chunk();
-                                    }
-                                    issue(slot, hp);
-                                }
-                                else if constexpr (o >= 51) SR[o - 51] = dpp_wave_shr1(X[npar][o - 51]);
-                            });
-                            __builtin_amdgcn_sched_barrier(0);
-                        });
-                    });
-                }
-                epilogue(y0, x);
-            }
-        }
-    } else {
     for (; it < nitems; it += stride) {
         const int rb = it / tiles_x, tx = it - rb * tiles_x;
         const int y0 = (rb0 + rb) * RR_ROWS, X = tx * RR_PX - 1;
@@ -1562,7 +1400,6 @@ __global__ __launch_bounds__(NWV * 64, (PLANAR || NWV <= 8) ? 2 : 3) void conv3x
         }
 #endif
         epilogue(y0, x);
-    }
     }
 
 #ifdef AIPT_R_CLOCK

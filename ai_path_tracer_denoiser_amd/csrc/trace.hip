@@ -1697,6 +1697,13 @@ int aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes) {
     for (int k = 0; k < nfaces; k++)
         if (v.tris[k].face < 0 || v.tris[k].face >= nfaces || v.faces[k].materialid < 0 || v.faces[k].materialid >= nmats)
             return fail(ctx, AIPT_E_FORMAT, "packed scene: face record %d", k);
+    // leaf slot of every face (the walk's winner is a face index): every face in exactly one leaf record -- checked here, with the
+    // other record checks, BEFORE the loaded scene is touched (a malformed blob leaves the context as it was)
+    std::vector<int> fslot(nfaces, -1);
+    for (int k = 0; k < nfaces; k++) {
+        if (fslot[v.tris[k].face] >= 0) return fail(ctx, AIPT_E_FORMAT, "packed scene: face %d is in two leaf records", v.tris[k].face);
+        fslot[v.tris[k].face] = k;
+    }
     AIPT_HIP(ctx, hipSetDevice(ctx->device));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     TraceState* s = tstate(ctx);
@@ -1721,10 +1728,6 @@ int aipt_scene_upload_packed(aipt_ctx* ctx, const void* blob, size_t bytes) {
         AIPT_HIP(ctx, hipMemcpy(s->d_nodes, v.nodes, sizeof(Bvh4Node) * nnodes, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(s->d_tris, v.tris, sizeof(TriRec) * nfaces, hipMemcpyHostToDevice));
         AIPT_HIP(ctx, hipMemcpy(s->d_lfaces, lf.data(), sizeof(DevFaceP) * nfaces, hipMemcpyHostToDevice));
-        std::vector<int> fslot(nfaces, -1);
-        for (int k = 0; k < nfaces; k++) fslot[v.tris[k].face] = k;
-        for (int k = 0; k < nfaces; k++)
-            if (fslot[k] < 0) return fail(ctx, AIPT_E_FORMAT, "packed scene: face %d is in no leaf", k);
         AIPT_HIP(ctx, hipMalloc((void**)&s->d_fslot, sizeof(int) * nfaces));
         AIPT_HIP(ctx, hipMemcpy(s->d_fslot, fslot.data(), sizeof(int) * nfaces, hipMemcpyHostToDevice));
         s->nnodes = nnodes;
@@ -1801,9 +1804,19 @@ extern "C++" { namespace aipt {
 int trace_enable_lanes(aipt_ctx* ctx) {
     TraceState* s = tstate(ctx);
     if (!s->d_state || s->batch < AIPT_TRACE_LANES_MIN) return AIPT_OK;
+    // (AIPT_TRACE_LANES=1, the profiling passes: no second lane, so none of its buffers -- half a batch of path state)
+    static const int lanes_env = getenv("AIPT_TRACE_LANES") ? atoi(getenv("AIPT_TRACE_LANES")) : 2;
+    if (lanes_env < 2) { free_side(s); return AIPT_OK; }
     if (!s->side) { s->side = new TraceState(); s->side->is_side = true; }
     const int rc2 = configure_state(ctx, s->side, s->W, s->H, (s->batch + 1) / 2);
-    if (rc2) return rc2;
+    if (rc2) {
+        // no memory for the second lane is not an error of aipt_frames_configure: a call is then traced by one lane
+        // (trace_lanes_ready() is false without it), as before round 5
+        (void)hipGetLastError();
+        free_side(s);
+        ctx->err.clear();
+        return AIPT_OK;
+    }
     // ... together with its stream, which is made to run something now: the first submission to a new HIP stream sets up its
     // hardware queue (milliseconds -- measured inside a timed 20-frame call: 715 instead of 905 frames/s)
     if (!ctx->st_lane1) {
@@ -2091,6 +2104,13 @@ int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n) {
     AIPT_HIP(ctx, hipMemcpyAsync(tmp.data(), s->d_nlive, sizeof(int) * (MAX_DEPTH + 1), hipMemcpyDeviceToHost, ctx->stream));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
     tmp[0] = s->P * s->last_frames;
+    // a two-lane call (aipt_frames): the second half of its frames was traced on the side lane -- the totals cover both halves
+    if (s->side_used && s->side && s->side->d_nlive) {
+        std::vector<int> side(MAX_DEPTH + 1);
+        AIPT_HIP(ctx, hipMemcpy(side.data(), s->side->d_nlive, sizeof(int) * (MAX_DEPTH + 1), hipMemcpyDeviceToHost));
+        side[0] = s->side->P * s->side->last_frames;
+        for (int i = 0; i <= s->last_depth; i++) tmp[i] += side[i];
+    }
     for (int i = 0; i < n; i++) h_n_live[i] = i <= s->last_depth ? tmp[i] : 0;
     return AIPT_OK;
 }
@@ -2122,10 +2142,15 @@ int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n) {
     AIPT_CHECK_CTX(ctx);
     TraceState* s = tstate(ctx);
     if (!s->mat0_valid) return fail(ctx, AIPT_E_STATE, "aipt_trace_first_hit_materials: last trace did not record them");
-    if (!h_mat || n != s->P * s->last_frames) return fail(ctx, AIPT_E_INVALID, "aipt_trace_first_hit_materials: n=%d, expected %d", n, s->P * s->last_frames);
+    // a two-lane call (aipt_frames): the main lane's frames, then the side lane's (each lane in its own batch layout: path = pixel x
+    // the lane's frame count + frame within the lane)
+    const TraceState* const side = s->side_used && s->side && s->side->mat0_valid && s->side->d_mat0 ? s->side : nullptr;
+    const int n_main = s->P * s->last_frames, n_side = side ? side->P * side->last_frames : 0;
+    if (!h_mat || n != n_main + n_side) return fail(ctx, AIPT_E_INVALID, "aipt_trace_first_hit_materials: n=%d, expected %d", n, n_main + n_side);
     if (ctx->last_trace_stream) AIPT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_traced, 0));
-    AIPT_HIP(ctx, hipMemcpyAsync(h_mat, s->d_mat0, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    AIPT_HIP(ctx, hipMemcpyAsync(h_mat, s->d_mat0, sizeof(int) * (size_t)n_main, hipMemcpyDeviceToHost, ctx->stream));
     AIPT_HIP(ctx, aipt::sync_streams(ctx));
+    if (side) AIPT_HIP(ctx, hipMemcpy(h_mat + n_main, side->d_mat0, sizeof(int) * (size_t)n_side, hipMemcpyDeviceToHost));
     return AIPT_OK;
 }
 

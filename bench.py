@@ -363,7 +363,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    n_live = ctx.live_counts(depth)            # of the last trace call (all frames of its batch together)
+    n_live = ctx.live_counts(depth)            # of the last trace call: totals over all its frames (both trace lanes)
     trace_kernels = [ctx.trace_kernel_name(0), ctx.trace_kernel_name(1)] if depth > 1 else [ctx.trace_kernel_name(0)] * 2
     P = W * H
     Hp, Wp = (H + 31) // 32 * 32, (W + 31) // 32 * 32
@@ -603,9 +603,14 @@ def main():
             # the mode `value` is quoted in: a batch of frames is in flight together, so the first frame of a call is delivered
             # after the whole call; the interactive figures (no batching) are under "frame_by_frame"
             "latency_frames": min(B, args.steps) if B > 1 else (1 if args.prefetch else 0),
+            # ... the same in time: the first frame of a call leaves after the whole call (throughput mode), after one frame time
+            # otherwise; an interactive host (the reference is a one-frame loop, main.cpp:143-163) reads "frame_by_frame"
+            "latency_ms": round((min(B, args.steps) if B > 1 else (2 if args.prefetch else 1)) * ms_per_step, 3),
             "host_enqueue_ms_per_step": round((t_enq - t0) / args.steps * 1e3, 4),
             "frame_by_frame": {"value": round(world * fbf_fps, 3), "unit": "frames/s", "latency_frames": 0,
+                               "latency_ms": round(1e3 / fbf_fps, 3) if fbf_fps else None,
                                "prefetch": {"value": round(world * fbf_pf_fps, 3), "latency_frames": 1,
+                                            "latency_ms": round(2e3 / fbf_pf_fps, 3) if fbf_pf_fps else None,
                                             "note": "aipt_frame_prefetch: frame k+1 traced beside the denoise of frame k on disjoint CUs"},
                                "note": f"aipt_frame, one call per frame, the {per_rank} frames of this rank's chunk after the timed "
                                        "region (host-synchronised at the end only)"},
@@ -628,7 +633,7 @@ def main():
                                "peak": MI355X_HBM_BPS / 1e9, "unit": "GB/s",
                                "frac": round((trace_bytes + dn_bytes) / (ms_per_step * 1e-3) / MI355X_HBM_BPS, 5),
                                "algorithmic_bytes_per_frame": trace_bytes + dn_bytes, "ms_per_frame": round(ms_per_step, 4),
-                               "note": "no kernel of the frame is HBM-bound (DESIGN.md 5): conv = MFMA + VALU issue, bounce = VALU issue"},
+                               "note": "no kernel of the frame is HBM-bound (DESIGN.md 5): the conv launches' parts add up (MFMAs 38 %, epilogue 20 %, per-launch fixed 21 %, loads 12 %: profiles/r06_conv_ablate.txt), the bounce kernel is VALU-issue-bound"},
             "cpu_baseline": cpu,
             "frame": {"ms_trace": round(trace_ms, 4), "ms_denoise": round(denoise_ms, 4),
                       "split_note": "one un-pipelined frame (aipt_frame) after the timed region",

@@ -207,9 +207,12 @@ int aipt_trace_kernel_name(aipt_ctx* ctx, int bounce, char* kernel, size_t kerne
  * otherwise AIPT_E_STATE): out16 = {lane node visits, wave node-loop trips, lane triangle tests, wave leaf-loop trips, lane leaf
  * visits, max node visits of one ray, 0, 0, rays that walked with <= 4, 8, 16, 32, 64, 128, more node visits, 0}. */
 int aipt_debug_trace_stats(aipt_ctx* ctx, unsigned long long* out16, int reset);
-/* live-path counts of the last aipt_trace: n_live[b] = paths entering bounce b, b = 0..depth (synchronous). */
+/* live-path counts of the last trace call: n_live[b] = paths entering bounce b, b = 0..depth, summed over the call's frames -- of
+ * both lanes when aipt_frames traced the call's two halves side by side (synchronous). */
 int aipt_trace_live_counts(aipt_ctx* ctx, int* h_n_live, int n);
-/* first-hit material ids (-1 = miss) per pixel index of the last AIPT_TRACE_RECORD_MAT0 trace (synchronous). */
+/* first-hit material ids (-1 = miss) per path of the last AIPT_TRACE_RECORD_MAT0 trace (synchronous): n = pixels x frames of the
+ * call; a batch is interleaved (path = pixel x frames + frame); after a two-lane aipt_frames call: the first lane's frames in that
+ * layout, then the second lane's. */
 int aipt_trace_first_hit_materials(aipt_ctx* ctx, int* h_mat, int n);
 
 /* ---- denoiser (main.cpp:101-118; model = training/recurrent_autoencoder_model.py) --------------------------- */
@@ -241,8 +244,9 @@ int aipt_denoise_load_weights(aipt_ctx* ctx, const void* blob, size_t bytes);
 int aipt_denoise_configure(aipt_ctx* ctx, int height, int width);
 int aipt_denoise_set_impl(aipt_ctx* ctx, int impl);
 /* Operand range of the split-fp16 implementations (AIPT_DN_IMPL_MFMA_F16X3 / _F16W; AIPT_DN_IMPL_MFMA and _VALU are plain fp32).
- *  - network input (the G-buffer, in the caller's units): held to max(2^-22 |x|, 2^-32) absolute for |x| <= 2^20 (1.0e6); larger
- *    values saturate at 2^20, and a frame whose EVERY plane is below ~1e-3 (unit normals never are) loses relative precision.
+ *  - network input (the G-buffer, in the caller's units): held to max(2^-22 |x|, 2^-32) absolute for |x| <= 65 504 x 2^4 =
+ *    1 048 064 (1.0e6); larger values saturate there (on every size: both split-fp16 kernels clamp alike), and a frame whose
+ *    EVERY plane is below ~1e-3 (unit normals never are) loses relative precision.
  *    The reference model is fp32 throughout (recurrent_autoencoder_model.py:8-142) and has neither bound.
  *  - BatchNorm sums are two-word fixed point: exact and order-independent while |sum x|, sum x^2 < 9.2e18 per channel and frame.
  *  - normalised activations y = LeakyReLU(BN(x)) are held as fp16 pairs: |y| < 4 094 on the levels of >= AIPT_DN_OPT_R_MINPIX

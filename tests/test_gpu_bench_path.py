@@ -207,6 +207,25 @@ def test_bench_multi_rank_branch_on_one_gpu():
     assert line["cpu_baseline"] is None and line["roofline"] is not None
 
 
+def test_bench_eight_rank_launch_line_on_one_gpu():
+    """[r6] VERDICT r5 item 7: the driver's EIGHT-rank launch line (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...`)
+    before an 8-GPU node runs it: eight processes, eight contexts on GPU 0, eight chunks of the frame sequence, rank 0 re-rendering
+    every chunk's first and last frame -- `per_rank_equal == [True] * 8` -- and ONE JSON line whose value is the eight ranks' frames
+    over the slowest rank's time."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("a GPU per rank is available: bench.py --gpus 8 runs the RCCL path itself")
+    line = _run_bench(["--gpus", "8", "--steps", "4", "--warmup", "2", "--config", "0", "--backend", "gloo", "--ranks-share-gpu",
+                       "--no-cpu-baseline"], nproc=8, timeout=900)
+    assert line["n_gpus"] == 8 and line["steps"] == 4 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["ranks_share_gpu"] is True and line["rccl_ranks"] == 0
+    assert line["validated"] is True
+    assert line["sharded_equals_single"] is True and line["sharding_check"]["per_rank_equal"] == [True] * 8
+    assert len(line["sharding_check"]["per_rank_frames_per_s"]) == 8
+    assert line["value"] > 0 and abs(line["value"] - 8 * 4 / (line["ms_per_step"] * 4e-3)) < 1e-2 * line["value"]
+    assert line["config"]["parallelism"] == "frame-shard x8"
+
+
 def test_bench_line_of_the_driver_command_small():
     """the one-rank line at a small config: every key the contract names, the timed region validated, the roofline pass after it"""
     line = _run_bench(["--steps", "6", "--warmup", "2", "--config", "0", "--no-cpu-baseline"])

@@ -99,6 +99,48 @@ def test_register_staged_kernel_against_the_reference_model(ctx, golden_dir, nam
     SEEN.update(names)
 
 
+def test_register_staged_kernel_with_a_carried_hidden_state_against_the_reference_model(ctx, golden_dir):
+    """[r6] VERDICT r5 missing 2: the two big goldens above are single frames -- model(x, 0) zeroes the hidden tensors
+    (recurrent_autoencoder_model.py:121-128), so the hidden half of every layer2.0 input (`torch.cat((out1, self.hidden))`, :64-67)
+    multiplies zeros and conv3x3_f16x3r's hidden-channel weights met reference output only at <= 96x160, through the other kernel.
+    `b_carry_384x640`: model(x0, 0), model(x1, 1) run by the imported reference model; 131 072 strided samples over both frames +
+    per-frame per-channel fp64 moments.  Level 0 (enc1.l1 planar, enc1.l2a with its 32 hidden channels, enc1.l2b) must run on the
+    register-staged kernel, and frame 1 -- whose enc*.l2a read the carried state -- must be <= 1e-3 from the reference."""
+    g = np.load(os.path.join(golden_dir, "denoise_b_carry_384x640.npz"))
+    H, W, wseed, iseed, nfr, batch = [int(v) for v in g["meta"]]
+    assert nfr == 2 and batch == 1
+    blob = synth.make_blob(wseed)
+    xs = [synth.make_gbuffer(H, W, iseed, j) for j in range(nfr)]
+    outs, names = _run(ctx, blob, xs, H, W, bn_batch=True, carry=True)
+    assert names[0] == R_PLANAR and names[1] == R and names[2] == R, names[:3]
+    y = np.stack(outs)
+    assert np.isfinite(y).all()
+    flat = y.reshape(-1)
+    idx = g["out_idx"]
+    per_frame = 3 * H * W
+    for j in range(nfr):
+        sel = (idx >= j * per_frame) & (idx < (j + 1) * per_frame)
+        assert sel.sum() > 60000
+        err = float(np.abs(flat[idx[sel]] - g["out_samples"][sel]).max())
+        y64 = y[j].astype(np.float64).reshape(3, -1)
+        np.testing.assert_allclose(y64.mean(axis=1), g["out_mean"][j], atol=2e-5)
+        np.testing.assert_allclose((y64 * y64).mean(axis=1), g["out_msq"][j], rtol=2e-4, atol=2e-5)
+        assert np.all(np.abs(np.abs(y64).max(axis=1) - g["out_absmax"][j]) <= TOL)
+        print(f"b_carry_384x640 frame {j}: max abs err vs the reference model {err:.2e}")
+        assert err <= TOL, (j, err)
+    # the carried state itself: the six hidden tensors after frame 1 against the reference's summaries
+    import torch
+    for lvl, shp in enumerate(arch.hidden_shapes(H, W)):
+        h = torch.empty(*shp, device="cuda")
+        ctx.get_hidden(lvl, h)
+        ctx.sync()
+        hh = h.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(hh.reshape(shp[0], -1).mean(axis=1), g[f"h{lvl}_mean"], atol=1e-3, rtol=1e-3)
+        np.testing.assert_allclose(hh.reshape(-1)[g[f"h{lvl}_idx"]], g[f"h{lvl}_samples"],
+                                   atol=TOL * max(1.0, float(np.abs(g[f"h{lvl}_samples"]).max())))
+    SEEN.update(names)
+
+
 @pytest.mark.parametrize("scale", [500.0, 5000.0])
 @pytest.mark.parametrize("size", [(384, 640), (736, 1280)])
 def test_large_magnitude_inputs_on_the_register_staged_kernel(ctx, size, scale):
@@ -116,17 +158,20 @@ def test_large_magnitude_inputs_on_the_register_staged_kernel(ctx, size, scale):
     print(f"{H}x{W} inputs x{scale:g}: max abs err vs the oracle {errs[0]:.2e}")
 
 
+@pytest.mark.parametrize("size", [(384, 640), (96, 160)])
 @pytest.mark.parametrize("peak", [1.0e6, 3.0e6])
-def test_network_inputs_up_to_and_beyond_2_pow_20(ctx, peak):
-    """[r5] include/aiptd.h: the G-buffer is held for |x| <= 2^20 (1.0e6) and saturates beyond.  Two defects of the planar
+def test_network_inputs_up_to_and_beyond_2_pow_20(ctx, peak, size):
+    """[r5] include/aiptd.h: the G-buffer is held for |x| <= 65 504 x 2^4 = 1 048 064 (1.0e6) and saturates beyond.  Two defects of the planar
     conv3x3_f16x3r found with these inputs (rounds 3-4 tested up to 1.25e5 only):
       * from |x| = 2^19 the round-toward-zero hi half left a remainder of up to a whole fp16 ulp (32), whose 2^11-scaled low half
         rounded to fp16 inf for one value in ~4 000 -- inf times a zero pad weight is NaN, and the BatchNorm sums spread it over the
         frame (a frame with first-hit distances up to 1.0e6 came out all NaN); the hi half is now rounded to nearest;
       * beyond 2^20 the hi half saturated but the low half of the UNclamped value overflowed; the value is now clamped
         to +-65 504 x 2^4 before the split.
-    Expected: the oracle's result on the input clipped to +-65 504 x 2^4 (no clipping happens at peak 1.0e6)."""
-    H, W = 384, 640
+    Expected: the oracle's result on the input clipped to +-65 504 x 2^4 (no clipping happens at peak 1.0e6).
+    [r6] 96x160: the LDS-tiled kernel's planar stash (frames below 200 000 pixels) clamps at the same value (it had no
+    clamp, so a frame beyond the range meant something else there)."""
+    H, W = size
     blob = synth.make_blob(565)
     x = synth.make_gbuffer(H, W, 3, 0)
     x[6] *= np.float32(peak / float(np.abs(x[6]).max()))             # first-hit distance up to `peak`
@@ -134,7 +179,7 @@ def test_network_inputs_up_to_and_beyond_2_pow_20(ctx, peak):
     lim = np.float32(65504.0 * 16.0)
     assert (np.abs(x[6]) > 2.0**19).mean() > 0.05 and ((np.abs(x[6]) > lim).mean() > 0.05) == (peak > 2e6)
     outs, names = _run(ctx, blob, [x], H, W, True, False)
-    assert names[0] == R_PLANAR, names[0]
+    assert names[0] == (R_PLANAR if H * W >= 200000 else "conv3x3_f16x3<1,8,true,false,1>"), names[0]
     assert np.isfinite(outs[0]).all()
     import oracle
     ref = oracle.DenoiseOracle(blob, H, W).forward(np.clip(x, -lim, lim), True, False)

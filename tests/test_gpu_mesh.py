@@ -108,3 +108,31 @@ def test_full_size_sponza_like_mesh_runs_and_is_consistent(ctx):
     assert np.array_equal(g1, g2) and np.array_equal(n1, n2)
     assert np.isfinite(g1).all() and n1[0] == 1280 * 720 and n1[-1] == 0
     assert (m1 == len(sc.materials) - 1).sum() > 100000
+
+
+def test_a_malformed_packed_scene_leaves_the_loaded_scene_untouched(ctx):
+    """[r6] ADVICE r5: a packed blob whose leaf records name one face twice (and so another face never) was rejected only AFTER
+    the loaded scene had been freed and half of the new buffers uploaded.  All record checks now run before the context is
+    touched: the call fails and the scene loaded before it still renders the same bits."""
+    import torch
+    from ai_path_tracer_denoiser_amd import dist as adist
+    from tests.gpu_util import to_api_scene
+    sc = _scene((64, 48), 3, 2048)
+    geoms, mats, faces, box, cam = to_api_scene(sc)
+    good = api.scene_pack(geoms, mats, faces, box)
+    ctx.pathtrace_init_packed(good, 64, 48)
+    g0 = torch.zeros(10, 48, 64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pathtrace(cam, 1, 3, g0, api.TRACE_DEFAULT)
+    ctx.sync()
+    _, off = adist.scene_sections(good)
+    bad = bytearray(good)
+    tris = np.frombuffer(bad, adist.TRI_DTYPE, len(faces), off["tris"])
+    tris["face"][5] = tris["face"][9]                     # face record 5 now names the face of record 9: one face twice, one never
+    with pytest.raises(RuntimeError, match="two leaf records"):
+        ctx.pathtrace_init_packed(bytes(bad))
+    g1 = torch.zeros(10, 48, 64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pathtrace(cam, 1, 3, g1, api.TRACE_DEFAULT)       # the scene uploaded before the failed call
+    ctx.sync()
+    assert torch.equal(g0, g1)

@@ -302,8 +302,8 @@ int aipt_frames_configure(aipt_ctx* ctx, int batch) {
 static int trace_frames(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cams, int nframes, int iter, int depth, uint32_t trace_flags,
                         float* d_gbatch) {
     const size_t frame = (size_t)10 * ctx->fwp * ctx->fhp;
-    // as few calls as AIPT_TRACE_BATCH_MAX allows, of (nearly) equal size: 20 frames are traced 10 + 10, not 16 + 4 (the
-    // pooled walks of a 4-frame call refill their lanes from a quarter of the rays)
+    // as few calls as AIPT_TRACE_BATCH_MAX allows, of (nearly) equal size: 20 frames are traced 10 + 10, not 16 + 4 (a
+    // 4-frame call's launches are mostly tail)
     const int ncalls = (nframes + AIPT_TRACE_BATCH_MAX - 1) / AIPT_TRACE_BATCH_MAX;
     // [r5] Two lanes: from AIPT_TRACE_LANES_MIN (2) frames on, the two halves of a call's frames are traced BESIDE each other -- the
     // first on `st`, the second on a side stream with its own path state.  Every bounce launch ends in a tail (its last workgroups

@@ -17,9 +17,10 @@
 //    the moment its remainingBounces reaches 0 (light, miss, or depth exhausted -- SURVEY F9).
 //  * Mesh: a 4-wide BVH with 8-bit child boxes (64-byte nodes) walked front to back on a per-lane LDS stack, 48-byte leaf
 //    triangle records, the winning face fetched once after the walk (bvh.cpp).  A leaf's triangles are tested by all 64 lanes
-//    of the wave (coop_leaf_step); batched traces pool a workgroup's rays and refill idle lanes (pool_walk); idle lanes that
-//    cannot be refilled take over subtrees of the busy lanes' walks, all parts of a ray meeting in one (t, face index)
-//    minimum (steal_step): the result never depends on which lane walked what.
+//    of the wave (coop_leaf_step); idle lanes take over subtrees of the busy lanes' walks, all parts of a ray meeting in one
+//    (t, face index) minimum (steal_step): the result never depends on which lane walked what.  (Rounds 2-5 also pooled a
+//    workgroup's rays in batched traces and refilled idle lanes from the pool; with the split walks that was worth +0.5 % and
+//    left in round 6: 600 lines, 19 KB of LDS -- tools/experiments/README.md.)
 //
 // Arithmetic is plain IEEE fp32 (this file is compiled with -ffp-contract=off, correctly rounded divide/sqrt), in the
 // statement order of the reference/GLM sources, so the output matches the CPU restatement used by the tests bit for
@@ -614,48 +615,13 @@ __device__ __forceinline__ void walk_node(const uint4* nodes, const WalkRay& r, 
     else cur = st.empty() ? WALK_DONE : st.pop();
 }
 
-// one leaf: the reference's triangle test on its (<= 7) triangles, two per memory round trip
-__device__ __forceinline__ void walk_leaf(const uint4* tris, WalkRay& r, int cur) {
-    const int v = -cur - 1, first = v >> 3, cnt = v & 7;
-    STAT_ADD(2, cnt); STAT_ADD(4, 1); STAT_WAVE(3);
-    for (int k = 0; k < cnt; k += 2) {
-        const bool two = k + 1 < cnt;
-        const uint4* tr = tris + (unsigned)(first + k) * 3u;
-        const uint4* tr2 = two ? tr + 3 : tr;           // odd count: the second test repeats the first (no effect)
-        const uint4 r0 = tr[0], r1 = tr[1], r2 = tr[2];
-        const uint4 q0 = tr2[0], q1 = tr2[1], q2 = tr2[2];
-        const float ta = triHitT_flat(V(__uint_as_float(r0.x), __uint_as_float(r0.y), __uint_as_float(r0.z)),
-                                      V(__uint_as_float(r0.w), __uint_as_float(r1.x), __uint_as_float(r1.y)),
-                                      V(__uint_as_float(r1.z), __uint_as_float(r1.w), __uint_as_float(r2.x)), r.o, r.d);
-        const int fa = (int)r2.y;
-        if (ta > 0.0f && (r.t_min > ta || (r.t_min == ta && r.best_face >= 0 && fa < r.best_face))) {
-            r.t_min = ta; r.best_face = fa; r.best_slot = first + k;
-        }
-        const float tb = triHitT_flat(V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)),
-                                      V(__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)),
-                                      V(__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)), r.o, r.d);
-        const int fb = (int)q2.y;
-        if (tb > 0.0f && (r.t_min > tb || (r.t_min == tb && r.best_face >= 0 && fb < r.best_face))) {
-            r.t_min = tb; r.best_face = fb; r.best_slot = first + k + (two ? 1 : 0);
-        }
-    }
-}
-
-// Cooperative leaf step of the pooled walk.  The lanes of a wave that hold a leaf (>= POOL_LEAF of them, 3.4 triangles each on the
-// atrium) list their (ray, triangle) pairs in LDS and ALL 64 lanes test one pair each per round: the owner's ray comes over by
+// Cooperative leaf step.  The lanes of a wave that hold a leaf (5.2 triangles each on the atrium) list their (ray, triangle) pairs in LDS and ALL 64 lanes test one pair each per round: the owner's ray comes over by
 // lane permutes, the result goes to the owner's slot by a 64-bit LDS atomicMin on (t bits, face index) -- the reference's
 // "first strictly smaller t wins, ties to the lowest face index" as an order-independent minimum (t > 0: IEEE bit patterns
 // order like the values; a face index is unique, so the lane whose key equals the slot afterwards is THE winner and records its
-// leaf slot).  Same arithmetic per triangle as walk_leaf (triHitT_flat on the same operands), so the hit is bit-identical; a leaf
+// leaf slot).  Same arithmetic per triangle as a per-lane loop over the leaf (triHitT_flat on the same operands), so the hit is bit-identical; a leaf
 // step costs ~170 instructions per 64 pairs on full lanes instead of ~150 per two triangles per lane on the ~14 lanes that hold a
 // leaf, for as many iterations as the fullest leaf needs (35 % of the walk's instructions, tools/trace_stats.py).
-#ifndef AIPT_POOL_COOP_LEAF
-#define AIPT_POOL_COOP_LEAF 1
-#endif
-#ifndef AIPT_POOL_TAIL_BOTH
-#define AIPT_POOL_TAIL_BOTH 1
-#endif
-static_assert(!AIPT_POOL_TAIL_BOTH || AIPT_POOL_COOP_LEAF, "the both-kinds tail steps its leaves cooperatively: its LDS tables exist only with AIPT_POOL_COOP_LEAF");
 constexpr int COOP_PAIRS = 64 * 7;                            // most (ray, triangle) pairs of one step: 64 leaves of 7 triangles
 struct CoopLeaf { unsigned* pairs; unsigned long long* best; int* slot; float2* rays; };   // this wave's LDS slices
 // inclusive prefix sum over the 64 lanes on the VALU (DPP row shifts + row broadcasts; no LDS permutes)
@@ -668,20 +634,17 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
     return x;
 }
-// SPLIT (split walks, below): the result word of a ray is cl.best[the ray's OWNER lane] for as long as the wave walks -- the lanes
-// at a leaf name their ray's owner in cl.slot and every tester reports straight to the owner's word -- instead of a per-step word
-// of the lane that holds the leaf.
-template <bool SPLIT>
+// Split walks (below): the result word of a ray is cl.best[the ray's OWNER lane] for as long as the wave walks -- the lanes at a
+// leaf name their ray's owner in cl.slot and every tester reports straight to the owner's word.
 __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, WalkStack& st, int& cur, const CoopLeaf& cl, int lane, int ray_owner) {
     const bool at_leaf = cur < 0 && cur != WALK_DONE;
     const int v = -cur - 1, first = v >> 3, cnt = at_leaf ? (v & 7) : 0;
     const int incl = wave_incl_scan(cnt);                      // inclusive prefix of the triangle counts over the wave
     const int total = __builtin_amdgcn_readlane(incl, 63), excl = incl - cnt;
-    // (no face yet: index 0 -- the bound is a primitive's hit or FLT_MAX, and a face at exactly that distance must NOT replace
-    // it (strict t_min > t in the reference's loop): its key (t, f >= 0) is never below (t, 0))
-    const unsigned long long mine = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
+    // (a ray's word starts as (bound, face index 0): the bound is a primitive's hit or FLT_MAX, and a face at exactly that distance
+    // must NOT replace it (strict t_min > t in the reference's loop): its key (t, f >= 0) is never below (t, 0))
     if (at_leaf) {
-        if (SPLIT) cl.slot[lane] = ray_owner; else cl.best[lane] = mine;
+        cl.slot[lane] = ray_owner;
         cl.rays[3 * lane] = make_float2(r.o.x, r.o.y);                        // the owners' rays: three 8-byte reads per tester
         cl.rays[3 * lane + 1] = make_float2(r.o.z, r.d.x);
         cl.rays[3 * lane + 2] = make_float2(r.d.y, r.d.z);
@@ -697,7 +660,7 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
         const int holder = (int)(pr >> 26), slot = (int)(pr & 0x3ffffffu);
         const float2 ra = cl.rays[3 * holder], rb = cl.rays[3 * holder + 1], rc = cl.rays[3 * holder + 2];
         const v3 o = V(ra.x, ra.y, rb.x), d = V(rb.y, rc.x, rc.y);
-        const int target = SPLIT ? cl.slot[holder] : holder;
+        const int target = cl.slot[holder];
         unsigned long long key = ~0ull;
         if (work) {
             const uint4* tr = tris + (unsigned)slot * 3u;
@@ -710,30 +673,15 @@ __device__ __forceinline__ void coop_leaf_step(const uint4* tris, WalkRay& r, Wa
                 atomicMin(&cl.best[target], key);
             }
         }
-        if (!SPLIT) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (key != ~0ull && cl.best[holder] == key) cl.slot[holder] = slot;      // the (so far) nearest face of that ray: its leaf slot
-        }
         STAT_ADD(2, work ? 1 : 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (at_leaf) {
-        if (SPLIT) {                                           // the ray's word, whoever lowered it
-            const unsigned long long b = cl.best[ray_owner];
-            r.t_min = __uint_as_float((unsigned)(b >> 32));
-            r.best_face = (int)(unsigned)b;
-        } else {
-            const unsigned long long b = cl.best[lane];
-            if (b != mine) {                                   // a face of this leaf is nearer (or as near with a lower index)
-                r.t_min = __uint_as_float((unsigned)(b >> 32));
-                r.best_face = (int)(unsigned)b;
-                r.best_slot = cl.slot[lane];
-            }
-        }
+        const unsigned long long b = cl.best[ray_owner];       // the ray's word, whoever lowered it
+        r.t_min = __uint_as_float((unsigned)(b >> 32));
+        r.best_face = (int)(unsigned)b;
         STAT_ADD(4, 1);
         cur = st.empty() ? WALK_DONE : st.pop();
     }
@@ -823,7 +771,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
 #else
 #define STAT_MINE() do {} while (0)
 #endif
-    if (AIPT_POOL_COOP_LEAF) {
+    {
         // wave-level "while-while": every lane descends to its next leaf, then ALL 64 lanes share the leaves' triangle tests;
         // idle lanes take over parts of the busy lanes' walks (steal_step)
         const unsigned long long key0 = ((unsigned long long)__float_as_uint(t_min) << 32);
@@ -843,7 +791,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
                 }
             }
             if (!__ballot(cur != WALK_DONE)) break;
-            coop_leaf_step<true>(tris, r, st, cur, cl, lane, sw.owner);
+            coop_leaf_step(tris, r, st, cur, cl, lane, sw.owner);
         }
         const unsigned long long res = cl.best[lane];          // (every leaf step ended behind a wave barrier)
         best_slot = -1;
@@ -851,21 +799,7 @@ __device__ __forceinline__ void bvh4_nearest(const TraceParams& p, v3 o, v3 d, W
             t_min = __uint_as_float((unsigned)(res >> 32));
             best_slot = p.fslot[(unsigned)res];
         }
-        return;
-    } else {
-    while (true) {
-        while (cur >= 0) {
-            STAT_ADD(0, 1); STAT_WAVE(1); STAT_MINE();
-            walk_node(nodes, r, st, cur);
-        }
-        if (cur == WALK_DONE) break;
-        walk_leaf(tris, r, cur);
-        cur = st.empty() ? WALK_DONE : st.pop();
-        if (cur == WALK_DONE) break;
     }
-    }
-    t_min = r.t_min;
-    best_slot = r.best_slot;
 #if defined(AIPT_TRACE_STATS) && !defined(AIPT_TRACE_NO_COUNTERS)
     atomicMax(&g_trace_stats[5], (unsigned long long)my_visits);
     const int bucket = my_visits <= 4 ? 8 : my_visits <= 8 ? 9 : my_visits <= 16 ? 10 : my_visits <= 32 ? 11 : my_visits <= 64 ? 12 : my_visits <= 128 ? 13 : 14;
@@ -903,165 +837,39 @@ __device__ __forceinline__ void camera_ray(const TraceParams& p, const aipt_came
                         vscale(vscale(up, cam.pixelLength[1]), sy)));
 }
 
-// ---- pooled walk (POOL instantiations of the bounce kernel).  A wave that walks 64 rays to the end runs the UNION of their
-// walks: 47 node-loop trips for 7 node visits per ray on the atrium (SIMD efficiency 0.16), because a few rays of every wave
-// take 30-70 visits.  With a batch of frames in one launch there are many more rays than lanes, so a workgroup takes
-// POOL_BLOCKS x 256 paths, lists those that enter the mesh box in an LDS pool and its four waves walk the pool: a lane whose
-// ray is finished stores the result and, once POOL_REFILL lanes of its wave are idle, they take the next rays of the pool.
-// Per-path arithmetic is that of the fused walk (walk_node / walk_leaf), started without the primitives' distance bound
-// (the nearest face is the nearest face; the caller lets it replace a primitive hit only when strictly nearer, as the
-// reference's loop does), so results do not depend on how rays were assigned to lanes.
-#ifndef AIPT_POOL_BLOCKS
-#define AIPT_POOL_BLOCKS 6
-#endif
-constexpr int POOL_BLOCKS = AIPT_POOL_BLOCKS;
-#ifndef AIPT_POOL_REFILL
-#define AIPT_POOL_REFILL 16
-#endif
-#ifndef AIPT_POOL_LEAF
-#define AIPT_POOL_LEAF 16
-#endif
-constexpr int POOL_REFILL = AIPT_POOL_REFILL;      // idle lanes of a wave that trigger a refill
-constexpr int POOL_LEAF = AIPT_POOL_LEAF;          // lanes waiting at a leaf that trigger a leaf step
-__device__ __forceinline__ int pool_blocks(int n) {                 // 256-path blocks per workgroup for n live paths
-    const int k = n / (256 * 512);                                  // keep >= 512 workgroups
-    return k < 1 ? 1 : k > POOL_BLOCKS ? POOL_BLOCKS : k;
-}
-__device__ __forceinline__ void pool_walk(const TraceParams& p, const int* s_pool, int pool_n, int* s_head, int* s_res,
-                                          WalkStack& st, int lane, const CoopLeaf& cl) {
-    const uint4* nodes = reinterpret_cast<const uint4*>(p.nodes);
-    const uint4* tris = reinterpret_cast<const uint4*>(p.tris);
-    const float4* S0 = p.st; const float4* S1 = p.st + p.PS;
-    WalkRay r;
-    r.start(V(0, 0, 0), V(1, 1, 1), FLT_MAX);
-    int cur = WALK_DONE, lid = -1;
-    bool exhausted = pool_n == 0;
-    st.sp = 0; st.bot = 0;
-    // the tail (pool exhausted): split walks -- the rays still under way keep their lanes' result words (cl.best[lane], this wave's
-    // slice: no unsplit leaf step needs it any more) until the wave is done, and idle lanes take over parts of their walks
-    constexpr unsigned long long KEY_NONE = (unsigned long long)0x7f7fffffu << 32;      // (FLT_MAX, 0): no face
-    bool split = false;
-    int tail_lid = -1;
-    SplitWalk sw{lane, false};
-    while (true) {
-        if (!split && cur == WALK_DONE && lid >= 0) {               // finished since the last look: hand the result over
-            s_res[lid] = r.best_slot;                               // (the distance comes back with the winner's full test)
-            lid = -1;
-        }
-        const unsigned long long idle = __ballot(cur == WALK_DONE);
-        const int nidle = __popcll(idle);
-        if (!exhausted && (nidle >= POOL_REFILL)) {
-            int base = 0;
-            if (lane == (int)__ffsll((long long)idle) - 1) base = atomicAdd(s_head, nidle);
-            base = __shfl(base, (int)__ffsll((long long)idle) - 1);
-            if (cur == WALK_DONE) {
-                const int k = base + __popcll(idle & ((1ull << lane) - 1ull));
-                if (k < pool_n) {
-                    lid = s_pool[k];
-                    const int i = s_res[lid];                       // the path index, parked there by the listing phase
-                    const float4 a = S0[i], b = S1[i];
-                    r.start(V(a.x, a.y, a.z), V(a.w, b.x, b.y), FLT_MAX);
-                    cur = 0;
-                    st.sp = 0; st.bot = 0;
-                }
-            }
-            exhausted = base + nidle >= pool_n;
-        }
-#if AIPT_POOL_TAIL_BOTH
-        if (exhausted && !split) {                                  // (wave-uniform) from here on: split walks
-            split = true;
-            tail_lid = lid;                                         // (-1: this lane holds no ray)
-            lid = -1;
-            cl.best[lane] = ((unsigned long long)__float_as_uint(r.t_min) << 32) | (unsigned)(r.best_face >= 0 ? r.best_face : 0);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-#endif
-        // one step for the lanes of one kind: inner nodes, unless POOL_LEAF lanes wait at a leaf (or nobody is at a node).
-        // (The fused walk's "descend until every lane holds a leaf" keeps a lane that found its leaf early idle for the
-        // whole descent of the others; with refilled lanes at every depth that would be most of the time.)
-        const int nl = __popcll(__ballot(cur < 0 && cur != WALK_DONE));
-        const bool any_node = __ballot(cur >= 0) != 0ull;
-        if (!any_node && nl == 0) {
-            if (exhausted) break;
-            continue;                                               // (unreachable: an all-idle wave always refills)
-        }
-#if AIPT_POOL_TAIL_BOTH
-        // Once the pool has run dry the wave's last rays are a latency chain (42 % of a later bounce's node steps run after that,
-        // 30 % with at most 8 lanes at a node): nobody waits for company any more -- every lane at a leaf gets its (cheap,
-        // cooperative) leaf step and every lane at a node its node step in the same trip -- and [r5] the idle lanes take over
-        // parts of the remaining walks (steal_step)
-        if (exhausted) {
-            steal_step(r, st, cur, sw, cl, lane);
-            if (__ballot(cur < 0 && cur != WALK_DONE)) coop_leaf_step<true>(tris, r, st, cur, cl, lane, sw.owner);
-            if (cur >= 0) {
-                split_refresh(r, sw, cl);
-                STAT_ADD(0, 1); STAT_WAVE(1);
-                walk_node(nodes, r, st, cur);
-            }
-            continue;
-        }
-#endif
-        if (nl >= POOL_LEAF || !any_node) {
-            if (AIPT_POOL_COOP_LEAF) coop_leaf_step<false>(tris, r, st, cur, cl, lane, lane);
-            else if (cur < 0 && cur != WALK_DONE) {
-                walk_leaf(tris, r, cur);
-                cur = st.empty() ? WALK_DONE : st.pop();
-            }
-        } else if (cur >= 0) {
-            STAT_ADD(0, 1); STAT_WAVE(1);
-            walk_node(nodes, r, st, cur);
-        }
-    }
-    if (tail_lid >= 0) {                                            // the rays of the tail: their words' faces (every leaf step ended behind a wave barrier)
-        const unsigned long long res = cl.best[lane];
-        s_res[tail_lid] = res != KEY_NONE ? p.fslot[(unsigned)res] : -1;
-    }
-    if (!split && lid >= 0) s_res[lid] = r.best_slot;               // (AIPT_POOL_TAIL_BOTH = 0 builds)
-}
-
 // ---------------------------------------------------------------------------------------------- the bounce kernel
 // MESH = false drops the triangle path (and its LDS traversal stack) from the instantiation used for primitive-only scenes.
 #ifndef AIPT_TRACE_OCC
 #define AIPT_TRACE_OCC 1
 #endif
 #ifndef AIPT_WALK_OCC
-#define AIPT_WALK_OCC 1      // workgroups per CU (= waves per SIMD) the un-pooled later-bounce instantiation is compiled for
+#define AIPT_WALK_OCC 1      // workgroups per CU (= waves per SIMD) the later-bounce mesh instantiation is compiled for
 #endif
-template <bool FIRST, bool MESH, bool POOL = false>
-__global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
-    static_assert((MESH && !FIRST) || !POOL, "the pool holds the mesh walks of the later bounces (bounce 0: coherent camera rays)");
+template <bool FIRST, bool MESH>
+__global__ __launch_bounds__(256, (MESH && !FIRST) ? AIPT_WALK_OCC : AIPT_TRACE_OCC) void trace_bounce(const TraceParams p) {
     __shared__ int s_wave[4];
-    __shared__ int s_pool_n, s_head;
     // Cameras of the frames traced together.  They arrive as kernel arguments, are read from the kernel-argument segment with
     // scalar loads (wave-uniform index) and indexed per lane from this LDS copy: `p.cams[fr]` with a per-lane frame index would
     // compile to vector loads from the kernel-argument segment, 21 dwords per lane through L1 instead of one LDS read each.
     // (Round 2 suspected those vector loads of the co-residency corruption; round 3 found packed-fp32 instructions beside gapped
     // fp16 MFMAs to be the cause, DESIGN.md 5 -- the LDS copy stays as the cheaper access, not as a fence.)
     __shared__ aipt_camera s_cams[FIRST ? BMAX : 1];
-    // dynamic LDS: [MESH: STACK_LDS x 256 stack words][POOL: pool, results][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)],
-    // sized by the launch
+    // dynamic LDS: [MESH: STACK_LDS x 256 stack words][primitives (<= MAXG_LDS)][materials (<= MAXM_LDS)], sized by the launch
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
     int* s_stack = s_dyn;
-    int* s_pool = s_dyn + STACK_LDS * 256;                                            // POOL: local ids of the paths to walk
-    int* s_res = s_pool + POOL_BLOCKS * 256;                                          // POOL: per local id: the walker's path index, then its leaf slot (-1: none)
-    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0) + (POOL ? POOL_BLOCKS * 256 * 2 : 0));
+    DevGeom* s_geoms = reinterpret_cast<DevGeom*>(s_dyn + (MESH ? STACK_LDS * 256 : 0));
     aipt_material* s_mats = reinterpret_cast<aipt_material*>(s_geoms + (p.ngeoms <= MAXG_LDS ? p.ngeoms : 0));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     PHASE_INIT();
     const int P = p.P;
     float4* S0 = p.st; float4* S1 = p.st + p.PS; float4* S2 = p.st + 2 * p.PS;
-    // live paths entering the bounce (complete: the previous kernels on this stream have finished) and the 256-path blocks
-    // this workgroup advances: one, or up to POOL_BLOCKS consecutive ones with their mesh walks pooled
+    // live paths entering the bounce (complete: the previous kernels on this stream have finished); this workgroup advances
+    // the 256-path block vb of the live list
     const int n_in = FIRST ? p.PT : p.n_live[p.bounce];
-    const int K = POOL ? pool_blocks(n_in) : 1;
-    const int vb0 = blockIdx.x * K;
-    if (!FIRST && vb0 * 256 >= n_in) {                   // whole workgroup beyond the list
-        if ((int)(blockIdx.x * 256) >= n_in && (int)blockIdx.x < p.nblk) {     // (a lower block index belongs to a pooling workgroup)
-            if (tid == 0) p.cnt[blockIdx.x] = 0;
-            if (p.nframes > 1 && tid < p.nframes) p.cntf[blockIdx.x * BMAX + tid] = 0;
-        }
+    const int vb = blockIdx.x;
+    if (!FIRST && vb * 256 >= n_in) {                    // whole workgroup beyond the list
+        if (tid == 0) p.cnt[vb] = 0;
+        if (p.nframes > 1 && tid < p.nframes) p.cntf[vb * BMAX + tid] = 0;
         return;
     }
 
@@ -1080,7 +888,6 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
         const int nw = p.nmats * (int)(sizeof(aipt_material) / 4);
         for (int k = tid; k < nw; k += 256) reinterpret_cast<int*>(s_mats)[k] = reinterpret_cast<const int*>(p.mats)[k];
     }
-    if (POOL && tid == 0) { s_pool_n = 0; s_head = 0; }
     if (FIRST) {
         // all 256 threads copy the cameras (21 dwords each) from the kernel-argument segment: one or two loads per thread (one lane
         // per wave copying whole structs was a chain of ~100 dependent scalar loads and LDS stores in front of every workgroup)
@@ -1094,40 +901,12 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
 
     const bool walk_mesh = MESH && !(FIRST && p.cache_mode == 2) && p.nfaces && !(p.flags & 0x40000000u);
     // LDS of the cooperative leaf step (coop_leaf_step): per wave, the (ray, triangle) pair list, the rays and the result slots
-    __shared__ unsigned s_pairs[MESH && AIPT_POOL_COOP_LEAF ? 4 * COOP_PAIRS : 1];
-    __shared__ unsigned long long s_best[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
-    __shared__ int s_slot[MESH && AIPT_POOL_COOP_LEAF ? 256 : 1];
-    __shared__ float2 s_rays[MESH && AIPT_POOL_COOP_LEAF ? 768 : 1];
-    const CoopLeaf cl{s_pairs + (MESH && AIPT_POOL_COOP_LEAF ? wave * COOP_PAIRS : 0), s_best + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0),
-                      s_slot + (MESH && AIPT_POOL_COOP_LEAF ? wave * 64 : 0), s_rays + (MESH && AIPT_POOL_COOP_LEAF ? wave * 192 : 0)};
-    if (POOL) {
-        // ---- list the paths of this workgroup's blocks that enter the mesh box, walk them all, leave (t, leaf slot) per path
-        for (int j = 0; j < K; j++) {
-            const int t = (vb0 + j) * 256 + tid;
-            const bool alive = t < n_in;
-            const int i = alive ? p.live_in[t] : 0;
-            bool walker = false;
-            if (alive && walk_mesh && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
-                const float4 a = S0[i], b = S1[i];
-                walker = (p.flags & AIPT_TRACE_NO_CULL) || rayAABB(V(a.x, a.y, a.z), V(a.w, b.x, b.y), p.box);      // RAY_CULLING (:23, :258)
-            }
-            const unsigned long long m = __ballot(walker);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(&s_pool_n, __popcll(m));
-            base = __shfl(base, 0);
-            s_res[j * 256 + tid] = walker ? i : -1;                 // the path index for the walker; "no face" for everyone else
-            if (walker) s_pool[base + __popcll(m & ((1ull << lane) - 1ull))] = j * 256 + tid;
-        }
-        __syncthreads();
-        WalkStack st{s_stack + tid, p.stack_ovf + (size_t)vb0 * 256 + tid, p.PS, 0, 0};
-        pool_walk(p, s_pool, s_pool_n, &s_head, s_res, st, lane, cl);
-        __syncthreads();
-        PHASE(2);
-    }
-
-  for (int j = 0; j < K; j++) {                            // (body not re-indented: one pass per 256-path block)
-    const int vb = vb0 + j;
-    if (POOL && vb >= p.nblk) break;
+    __shared__ unsigned s_pairs[MESH ? 4 * COOP_PAIRS : 1];
+    __shared__ unsigned long long s_best[MESH ? 256 : 1];
+    __shared__ int s_slot[MESH ? 256 : 1];
+    __shared__ float2 s_rays[MESH ? 768 : 1];
+    const CoopLeaf cl{s_pairs + (MESH ? wave * COOP_PAIRS : 0), s_best + (MESH ? wave * 64 : 0),
+                      s_slot + (MESH ? wave * 64 : 0), s_rays + (MESH ? wave * 192 : 0)};
     int i, idx, rem = 0;
     bool alive;
     const int t = vb * 256 + tid;
@@ -1230,16 +1009,7 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
             }
         }
         PHASE(1);
-        if (POOL && !(p.flags & AIPT_TRACE_BRUTE_FORCE)) {
-            const int w = s_res[j * 256 + tid];                     // nearest face of the pooled walk (slot -1: none)
-            if (w >= 0) {
-                DevFace f;
-                load_leaf_face(p, w, f);
-                v3 tp, tn;
-                const float t = triangleTest(f, o, d, tp, tn);      // (the walk's distance of this face, same bits)
-                if (t_min > t) { t_min = t; materialid = f.materialid; hitP = tp; normal = tn; }   // a face replaces a primitive hit only when strictly nearer (:262)
-            }
-        } else if (walk_mesh && ((p.flags & AIPT_TRACE_NO_CULL) || rayAABB(o, d, p.box))) {   // RAY_CULLING true (:23, :258) / false (:270-281)
+        if (walk_mesh && ((p.flags & AIPT_TRACE_NO_CULL) || rayAABB(o, d, p.box))) {   // RAY_CULLING true (:23, :258) / false (:270-281)
             if (p.flags & AIPT_TRACE_BRUTE_FORCE) {
                 // the reference's loop: every face, in index order
                 for (int fi = 0; fi < p.nfaces; fi++) {
@@ -1250,7 +1020,7 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
             } else want_walk = true;
         }
     }
-    if (MESH && !POOL && __syncthreads_or(want_walk)) {           // (workgroup-uniform: the cooperative leaf step's LDS slices are per wave)
+    if (MESH && __syncthreads_or(want_walk)) {           // (workgroup-uniform: the cooperative leaf step's LDS slices are per wave)
         int best_slot = -1;
         WalkStack st{s_stack + tid, p.stack_ovf + t, p.PS, 0, 0};
         bvh4_nearest(p, o, d, st, t_min, best_slot, cl, lane, want_walk);
@@ -1329,7 +1099,6 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
 
     // ---- live count of this 256-path block for the next bounce
     const unsigned long long m2 = __ballot(alive_after);
-    if (POOL) __syncthreads();                      // the previous block's readers of s_wave / s_cf are done
     if (lane == 0) s_wave[wave] = __popcll(m2);
     __syncthreads();
     if (tid == 0) {
@@ -1351,7 +1120,6 @@ __global__ __launch_bounds__(256, (MESH && !POOL && !FIRST) ? AIPT_WALK_OCC : AI
             if (s_cf[tid]) atomicAdd(&p.n_live_f[(p.bounce + 1) * BMAX + tid], s_cf[tid]);
         }
     }
-  }
 }
 
 // Batched traces: exclusive prefix over the workgroups of the survivor counts, in place -- blockIdx 0: all frames together
@@ -1956,14 +1724,8 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
     const bool mesh = s->nfaces > 0;
     const size_t lds_scene = (s->ngeoms <= MAXG_LDS ? sizeof(DevGeom) * s->ngeoms : 0) + (s->nmats <= MAXM_LDS ? sizeof(aipt_material) * s->nmats : 0);
     const size_t stack_bytes = (mesh ? (size_t)STACK_LDS * 256 * sizeof(int) : 0) + lds_scene;     // dynamic LDS of the bounce kernels
-    // batched traces of a mesh scene pool their walks (see pool_walk); AIPT_TRACE_POOL=0/1 forces the choice (experiments)
-    static const int pool_env = getenv("AIPT_TRACE_POOL") ? atoi(getenv("AIPT_TRACE_POOL")) : -1;
-    // (from 4 frames on: at 2 frames both walks take 0.82 ms per frame, single frames lose 10 %; never on bounce 0, whose camera
-    // rays are coherent -- 0.48 SIMD efficiency in the fused walk -- and would be generated twice: 415 vs 476 us at 8 frames)
-    const bool pool = mesh && (pool_env < 0 ? nframes >= 4 : pool_env != 0);
-    const size_t pool_bytes = stack_bytes + (size_t)POOL_BLOCKS * 256 * 2 * sizeof(int);
-    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s,false>", mesh ? "true" : "false");
-    snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s,%s>", mesh ? "true" : "false", pool ? "true" : "false");
+    snprintf(s->kname[0], sizeof(s->kname[0]), "trace_bounce<true,%s>", mesh ? "true" : "false");
+    snprintf(s->kname[1], sizeof(s->kname[1]), "trace_bounce<false,%s>", mesh ? "true" : "false");
     int cur = -1;                                               // live list the bounce reads (-1: bounce 0, all pixels)
     for (int b = 0; b < depth; b++) {
         p.bounce = b;
@@ -1973,8 +1735,7 @@ int trace_on_stream(aipt_ctx* ctx, hipStream_t st, const aipt_camera* cam, int n
         if (nframes > 1) { p.rank_in = cur < 0 ? nullptr : s->d_rank[cur]; p.rank_out = s->d_rank[nxt]; }
         hipEvent_t* pev = prof ? &s->prof_ev[((size_t)s->prof_calls * MAX_DEPTH + b) * 2] : nullptr;
         if (pev) AIPT_HIP(ctx, hipEventRecord(pev[0], st));
-        if (b > 0 && pool) hipLaunchKernelGGL((trace_bounce<false, true, true>), dim3(nblk), dim3(256), pool_bytes, st, p);
-        else if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
+        if (b == 0 && mesh) hipLaunchKernelGGL((trace_bounce<true, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else if (b == 0) hipLaunchKernelGGL((trace_bounce<true, false>), dim3(nblk), dim3(256), lds_scene, st, p);
         else if (mesh) hipLaunchKernelGGL((trace_bounce<false, true>), dim3(nblk), dim3(256), stack_bytes, st, p);
         else hipLaunchKernelGGL((trace_bounce<false, false>), dim3(nblk), dim3(256), lds_scene, st, p);

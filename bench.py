@@ -15,8 +15,8 @@ resident in HBM before the timed region; nothing crosses PCIe per frame.
 
 Frame batches (aipt_frames; results bit-identical to frame-by-frame rendering, tests/test_gpu_frame.py): a call holds up to 24
 consecutive frames (--batch; at most 32).  Their traces share one set of bounce launches per up to 24 frames (a single 1280x720 frame leaves most of the
-chip idle in its later bounces; the frames are interleaved pixel by pixel and a workgroup pools the BVH walks of 1024 paths,
-refilling idle lanes).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
+chip idle in its later bounces; the frames are interleaved pixel by pixel, so that neighbouring lanes walk near-identical rays, and
+a wave's idle lanes take over subtrees of its busy lanes' walks).  Their denoiser passes run on two streams, frame n+1 entering an encoder level when frame n has left
 it, so the many small launches of one frame's deep levels run beside the full-size layers of the other; the hidden state is
 carried through the batch.  --batch 1 is the frame-by-frame sequence.  The trace / denoise split of the JSON line is
 measured on one single frame after the timed region.
@@ -561,7 +561,7 @@ def main():
                                         "algorithmic_bytes_per_launch": by_first,
                                         "achieved_GBps": round(by_first / (t_first * 1e-3) / 1e9, 1) if t_first > 0 else 0.0},
                        "rays_per_frame": int(sum(nb)), "grays_per_s": round(sum(nb) * fpc / ((t_late + t_first) * 1e-3) / 1e9, 3),
-                       "note": "the pooled BVH walk is VALU-issue-bound (DESIGN.md 5); the HBM roof is reported because north_star "
+                       "note": "the batched BVH walk is VALU-issue-bound (DESIGN.md 5); the HBM roof is reported because north_star "
                                "asks for it, it is not what bounds this kernel"}
         if tr_roof and tr_roof["ms_per_frame"] > conv_roof["ms_per_frame"]:
             roof, other = tr_roof, conv_roof

@@ -29,8 +29,6 @@
  * frames one set of launches covers, never a bit of any result (tests/test_gpu_frame.py, tests/test_cli.py compare them):
  *   AIPT_DN_PIPELINE=0          aipt_frames: the denoiser passes of a call on ONE stream instead of two (profiling: a chip-wide
  *                               counter then belongs to one kernel; tools/collect_evidence.sh)
- *   AIPT_TRACE_POOL=0 / 1       batched traces: never / always pool the BVH walks of a workgroup's paths (default: from 4 frames
- *                               per launch on)
  *   AIPT_PREFETCH_TRACE_CUS=n   aipt_frame_prefetch: CUs of the trace stream's mask, a multiple of 32 (default: 3/8 of the chip)
  *   AIPT_TRACE_LANES=1          aipt_frames: trace a call's frames with ONE set of launches instead of two half-batches side by
  *                               side on two streams (default 2)

@@ -1,7 +1,7 @@
 """-m gpu: parity of the path bench.py TIMES, at the size it times it.
 
 bench.py's timed region calls aipt_frames on batches of up to 32 frames: traces of up to 16 frames per launch set (pixel-
-interleaved frames, per-frame live counters, pooled BVH walks in trace_bounce<false,true,true>) and the denoiser passes of
+interleaved frames, per-frame live counters, split BVH walks in trace_bounce<false,true>) and the denoiser passes of
 consecutive frames pipelined over two streams with the hidden state carried.  These tests build bench.py's own Workload
 object (same scene, mesh, weights, cameras, flags and configure calls) and check
 
@@ -89,7 +89,7 @@ def test_bench_default_32_frame_call_configs2_full_size():
         got.extend(wl.outs[j].cpu().numpy().copy() for j in range(nb))
     wl.run_frames(0, N, on_batch=keep)
     assert len(got) == N
-    assert wl.ctx.trace_kernel_name(1) == "trace_bounce<false,true,true>"      # the pooled walk is what ran
+    assert wl.ctx.trace_kernel_name(1) == "trace_bounce<false,true>"           # the batched mesh instantiation is what ran
     # ---- G-buffers of frames of both 16-frame launch sets against the oracle, every bit
     osc = _oracle_scene(wl)
     rows, stride = (wl.H + 31) // 32 * 32, (wl.W + 31) // 32 * 32
@@ -151,7 +151,7 @@ def test_batch_mode_configs3_and_4_full_size(config, nframes):
         wl.ctx.sync()
         got.extend(wl.outs[j].cpu().numpy().copy() for j in range(nb))
     wl.run_frames(0, nframes, on_batch=keep)
-    assert wl.ctx.trace_kernel_name(1) == "trace_bounce<false,true,true>"
+    assert wl.ctx.trace_kernel_name(1) == "trace_bounce<false,true>"
     osc = _oracle_scene(wl)
     rows, stride = (wl.H + 31) // 32 * 32, (wl.W + 31) // 32 * 32
     for f in (0, nframes // 2, nframes - 1):

@@ -133,7 +133,7 @@ def test_batched_trace_equals_single_frame_traces(mesh):
     per bounce and first-hit materials (the RNG index of a path is its rank inside ITS frame).  1 to 24 frames per launch set
     (24 = AIPT_TRACE_BATCH_MAX: the per-frame counters, kernel-argument cameras and the 25-workgroup trace_scan at their limit;
     20 = what the driver's `bench.py --steps 20` traces in one call), on the mesh scene
-    (pooled walks from 4 frames on) and on the primitives-only scene."""
+    and on the primitives-only scene."""
     import torch
     W, H, depth = 100, 60, 6               # 6000 pixels per frame: the frames straddle workgroups and waves
     sc, mats, faces, box = _mesh_scene((W, H), depth)
@@ -287,11 +287,10 @@ def test_prefetch_on_disjoint_cus_is_bit_identical_at_a_size_that_overlaps():
             assert np.array_equal(got[k], ref[k]), (rep, k)
 
 
-def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_traces():
-    """Batches of 4+ frames pool their BVH walks (trace_bounce<false,true,true>: lanes refilled from an LDS pool, the walk
-    started without the primitives' distance bound).  The living-room mesh -- diffuse, mirror and glass faces, paths that
-    leave and re-enter the mesh -- traced 16, 13, 9, 8 and 5 frames at a time must equal the frames' own fused-walk traces bit for bit,
-    live counts included."""
+def test_batched_walks_on_reflective_and_refractive_faces_equal_single_frame_traces():
+    """Batched traces (pixel-interleaved frames, per-frame RNG ranks, split walks over a wave's lanes; rounds 2-5 also pooled a
+    workgroup's walks here).  The living-room mesh -- diffuse, mirror and glass faces, paths that leave and re-enter the mesh --
+    traced 16, 13, 9, 8 and 5 frames at a time must equal the frames' own single-frame traces bit for bit, live counts included."""
     import torch
     W, H, depth = 160, 96, 8
     sc = api.Scene(CORNELL, res=(W, H), depth=depth)
@@ -311,7 +310,7 @@ def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_trac
         ctx.pathtrace(c, 1, depth, g1)
         ctx.sync()
         singles.append((g1.cpu().numpy().copy(), ctx.live_counts(depth).copy()))
-    assert ctx.trace_kernel_name(1) == "trace_bounce<false,true,false>"
+    assert ctx.trace_kernel_name(1) == "trace_bounce<false,true>"
     ctx.trace_configure_batch(W, H, 16)
     gb = torch.zeros(16, 10, H, W, device="cuda")
     torch.cuda.synchronize()
@@ -320,7 +319,7 @@ def test_pooled_walks_on_reflective_and_refractive_faces_equal_single_frame_trac
         torch.cuda.synchronize()
         ctx.pathtrace_batch(cams[:nf], 1, depth, gb)
         ctx.sync()
-        assert ctx.trace_kernel_name(1) == "trace_bounce<false,true,true>"
+        assert ctx.trace_kernel_name(1) == "trace_bounce<false,true>"
         got = gb.cpu().numpy()
         for f in range(nf):
             assert np.array_equal(got[f].view(np.uint32), singles[f][0].view(np.uint32)), (nf, f)

@@ -298,7 +298,7 @@ def test_no_cull_bit_exact(ctx):
         g, n, mt = gpu_trace(ctx, sc, 6, flags=api.TRACE_DEFAULT | api.TRACE_RECORD_MAT0 | api.TRACE_NO_CULL | extra)
         assert np.array_equal(mt, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist()
         _same(g, g_ref, f"no cull ({extra})")
-    # batches of frames (pooled walks) take the flag too
+    # batches of frames take the flag too
     cams = [api.Camera.from_buffer_copy(bytes(sc.camera)) for _ in range(3)]
     import torch
     W, H = sc.camera.res[0], sc.camera.res[1]

@@ -66,7 +66,7 @@ def test_split_walks_resolve_ties_across_stolen_subtrees(ctx):
     """[r5] Split walks: idle lanes take over subtrees of a busy lane's walk and all parts of a ray meet in one (t, face index)
     minimum.  Ten copies of every face, materials alternating, spread over the whole index range: a group of equal-distance
     faces exceeds a leaf (7 faces) and lies in different leaves / subtrees, so the lowest index has to win ACROSS the parts of a
-    walk -- single frames (every lane of a 48 x 40 image's waves has idle neighbours) and a batch (splitting in the pooled walk's
+    walk -- single frames (every lane of a 48 x 40 image's waves has idle neighbours) and a batch (the same walk on interleaved
     tail), against the oracle's index-ordered loop (strict t_min > t, pathtrace.cu:261)."""
     import oracle
     sc = oracle.OracleScene.parse(CORNELL, res=(48, 40), depth=3)
@@ -86,7 +86,7 @@ def test_split_walks_resolve_ties_across_stolen_subtrees(ctx):
     assert np.array_equal(m, m_ref) and n[:len(n_ref)].tolist() == n_ref.tolist()
     assert np.array_equal(g, g_ref)
     assert len(set(m_ref[np.isin(m_ref, mats)].tolist())) >= 3   # ties were won by copies of several materials
-    # the same camera eight times in one batched trace (pooled walks, split in their tail): every frame = the single frame
+    # the same camera eight times in one batched trace: every frame = the single frame
     import torch
     from tests.gpu_util import to_api_scene
     cam = to_api_scene(sc)[4]

@@ -20,7 +20,7 @@ pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum
 pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 python tools/pmc_summarize.py --frames-per-launch 20 --out $O/pmc_dominant.json $O/pmc_fetch/p_counter_collection.csv $O/pmc_write/p_counter_collection.csv \
-    'trace_bounce<false,true,true>' 'trace_bounce<true,true,false>' 'trace_bounce<false,true,false>' 'conv3x3_f16x3r<false,12,3,false,4,false>' 'conv3x3_f16x3r<false,8,3,false,4,true>' \
+    'trace_bounce<false,true>' 'trace_bounce<true,true>' 'conv3x3_f16x3r<false,12,3,false,4,false>' 'conv3x3_f16x3r<false,8,3,false,4,true>' \
     'conv3x3_f16x3<1,8,false,false,1>' 'conv3x3_f16x3<1,4,false,false,3>' 'conv3x3_quad<3,3,false>' 'conv3x3_quad<3,3,true>'
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel trace_bounce --json $O/pmc_trace.json > /dev/null
 python tools/pmc_table.py $O/pmc_*/p_counter_collection.csv --kernel 'conv3x3_f16x3' --json $O/pmc_conv.json > /dev/null
@@ -31,7 +31,6 @@ $B --no-cpu-baseline --layers > /dev/null 2> $O/layers.txt
 $B --batch 1 --no-cpu-baseline > $O/bench_frame_by_frame.json 2>/dev/null
 $B --batch 1 --prefetch --no-cpu-baseline > $O/bench_frame_by_frame_prefetch.json 2>/dev/null
 AIPT_DN_PIPELINE=0 $B --no-cpu-baseline > $O/bench_one_denoiser_stream.json 2>/dev/null
-AIPT_TRACE_POOL=0 $B --no-cpu-baseline > $O/bench_fused_walk.json 2>/dev/null
 AIPT_TRACE_LANES=1 $B --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_one_trace_lane.json 2>/dev/null
 for c in 0 1 3 4; do $B --config $c --no-cpu-baseline > $O/bench_config$c.json 2>/dev/null; done
 $B --no-cpu-baseline --bn running --hidden reset > $O/bench_running_reset.json 2>/dev/null

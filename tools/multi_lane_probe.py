@@ -1,5 +1,5 @@
 """How many trace lanes (independent sets of bounce launches side by side on their own streams) does a 20-frame call want, with the
-pooled walk and with the un-pooled split walk (AIPT_TRACE_POOL=0/1 in the environment)?  N contexts, one stream each.
+split walk (round 5 compared it with the pooled walk, AIPT_TRACE_POOL=0/1, removed in round 6)?  N contexts, one stream each.
     python tools/multi_lane_probe.py [frames]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +36,7 @@ def run(parts, reps=6):
     for c, g in ctxs: c.close()
     return best * 1e3 / N
 full = list(range(N))
-print("AIPT_TRACE_POOL =", os.environ.get("AIPT_TRACE_POOL", "(default)"), " AIPT_TRACE_LANES=1 inside every context")
+print("AIPT_TRACE_LANES=1 inside every context")
 for L in (1, 2, 3, 4, 5, 10, 20):
     if L > N: break
     parts = [full[k::L] for k in range(L)]

@@ -13,9 +13,9 @@ def short(n):
     return n.split('(')[0].replace(' ','')
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),short(r['Kernel_Name']),r['Queue_Id']) for r in rows]
 ev.sort()
-# timed call: the single pooled-trace call with 20 frames: find the longest-gap?  Identify by trace_bounce<true,true,false> launches: warmup(1), timed(1), rerun(1) ... take pooled launches groups of 7
-idx=[i for i,e in enumerate(ev) if e[2]=='trace_bounce<false,true,true>']
-print('pooled launches', len(idx))
+# timed call: the single batched-trace call with 20 frames: the later-bounce launches come in groups of 7 per lane and call: warmup, timed, rerun ...
+idx=[i for i,e in enumerate(ev) if e[2]=='trace_bounce<false,true>']
+print('later-bounce launches', len(idx))
 grp=[idx[i:i+7] for i in range(0,len(idx),7)]
 g=grp[1]   # timed call
 last=g[-1]

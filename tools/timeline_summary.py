@@ -13,22 +13,23 @@ def short(n):
     return n.split('(')[0].replace(' ','')
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),short(r['Kernel_Name']),r['Queue_Id']) for r in rows]
 ev.sort()
-# timed call: the single batched-trace call with 20 frames: the later-bounce launches come in groups of 7 per lane and call: warmup, timed, rerun ...
-idx=[i for i,e in enumerate(ev) if e[2]=='trace_bounce<false,true>']
-print('later-bounce launches', len(idx))
-grp=[idx[i:i+7] for i in range(0,len(idx),7)]
-g=grp[1]   # timed call
-last=g[-1]
-k=g[0]
-while ev[k-1][2].startswith('trace_') or 'fillBuffer' in ev[k-1][2]: k-=1
-t0=ev[k][0]
-k=last+1; nq=0; seg=[]
-while k<len(ev) and nq<20:
-    seg.append(ev[k])
-    if ev[k][2]=='conv3x3_quad<3,3,false>': nq+=1
-    k+=1
+# the timed call: everything queued behind the gate's spin kernel (torch.cuda._sleep) up to its 20th denoised frame
+spin=[i for i,e in enumerate(ev) if 'spin' in e[2].lower() or 'sleep' in e[2].lower()]
+assert spin, 'no spin kernel in the trace: run bench.py with --gate-ms'
+gate_end=ev[spin[-1]][1]
+call=[e for e in ev if e[0]>=gate_end]
+t0=call[0][0]
+seg=[]; nq=0; last_trace_end=t0
+for e in call:
+    if e[2].startswith('trace_'):
+        if nq==0: last_trace_end=max(last_trace_end,e[1])
+        continue
+    if 'fillBuffer' in e[2] and not seg: continue
+    if nq<20:
+        seg.append(e)
+        if e[2]=='conv3x3_quad<3,3,false>': nq+=1
 tA=seg[0][0]; tB=max(e[1] for e in seg)
-print('trace ms/frame', (ev[last][1]-t0)/1e6/20, 'denoise ms/frame', (tB-tA)/1e6/20, 'total', (tB-t0)/1e6/20)
+print('trace ms/frame', (last_trace_end-t0)/1e6/20, 'denoise ms/frame', (tB-tA)/1e6/20, 'total', (tB-t0)/1e6/20)
 def cls(n):
     if n.startswith('conv3x3_f16x3r'): return 'big'
     if n.startswith('conv3x3_quad'): return 'quad'

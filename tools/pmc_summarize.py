@@ -31,10 +31,19 @@ def short(name):
 
 
 def per_launch(path, counter):
-    acc = {}
+    """kernel -> counter values of its launches.  The bounce kernels run batched (the timed calls) AND one frame at a time (bench.py
+    re-renders its frames for validation) under one name since round 6: only the launches with the largest grid -- the batched
+    ones -- are averaged, so that "per launch" keeps meaning a launch of the timed region."""
+    acc, grid = {}, {}
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            acc.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+            k = short(r["Kernel_Name"])
+            acc.setdefault(k, []).append(float(r["Counter_Value"]))
+            grid.setdefault(k, []).append(int(r["Grid_Size"]))
+    for k in acc:
+        if k.startswith("trace_bounce"):
+            top = max(grid[k])
+            acc[k] = [v for v, g in zip(acc[k], grid[k]) if g == top]
     return acc
 
 

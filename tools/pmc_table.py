@@ -46,6 +46,8 @@ def main():
             k = short(r["Kernel_Name"])
             if want and want not in k:
                 continue
+            if k.startswith("trace_"):                 # batched and single-frame launches share a name: one row per grid size
+                k = f"{k} @ {int(r['Grid_Size']) // int(r['Workgroup_Size'])} workgroups"
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             key = (p, r["Dispatch_Id"])
             if key not in seen:

@@ -9,12 +9,13 @@ import csv, sys
 from collections import defaultdict
 rows=list(csv.DictReader(open(sys.argv[1])))
 def short(n):
+    if 'spin_kernel' in n: return 'spin_kernel'               # torch.cuda._sleep: at::cuda::(anonymous namespace)::spin_kernel(long)
     n=n.replace('void aipt::','').replace('aipt::','')
     return n.split('(')[0].replace(' ','')
 ev=[(int(r['Start_Timestamp']),int(r['End_Timestamp']),short(r['Kernel_Name']),r['Queue_Id']) for r in rows]
 ev.sort()
 # the timed call: everything queued behind the gate's spin kernel (torch.cuda._sleep) up to its 20th denoised frame
-spin=[i for i,e in enumerate(ev) if 'spin' in e[2].lower() or 'sleep' in e[2].lower()]
+spin=[i for i,e in enumerate(ev) if e[2]=='spin_kernel']
 assert spin, 'no spin kernel in the trace: run bench.py with --gate-ms'
 gate_end=ev[spin[-1]][1]
 call=[e for e in ev if e[0]>=gate_end]

@@ -99,19 +99,23 @@ def test_register_staged_kernel_against_the_reference_model(ctx, golden_dir, nam
     SEEN.update(names)
 
 
-def test_register_staged_kernel_with_a_carried_hidden_state_against_the_reference_model(ctx, golden_dir):
+@pytest.mark.parametrize("name", ["b_carry_384x640", "r_carry_384x640"])
+def test_register_staged_kernel_with_a_carried_hidden_state_against_the_reference_model(ctx, golden_dir, name):
     """[r6] VERDICT r5 missing 2: the two big goldens above are single frames -- model(x, 0) zeroes the hidden tensors
     (recurrent_autoencoder_model.py:121-128), so the hidden half of every layer2.0 input (`torch.cat((out1, self.hidden))`, :64-67)
     multiplies zeros and conv3x3_f16x3r's hidden-channel weights met reference output only at <= 96x160, through the other kernel.
     `b_carry_384x640`: model(x0, 0), model(x1, 1) run by the imported reference model; 131 072 strided samples over both frames +
     per-frame per-channel fp64 moments.  Level 0 (enc1.l1 planar, enc1.l2a with its 32 hidden channels, enc1.l2b) must run on the
-    register-staged kernel, and frame 1 -- whose enc*.l2a read the carried state -- must be <= 1e-3 from the reference."""
-    g = np.load(os.path.join(golden_dir, "denoise_b_carry_384x640.npz"))
+    register-staged kernel, and frame 1 -- whose enc*.l2a read the carried state -- must be <= 1e-3 from the reference.
+    `r_carry_384x640`: the same with running-statistics BatchNorm (model.eval(), training/test.py:35; outputs up to 30 with the
+    synthetic weights' identity statistics), same plain 1e-3 bar."""
+    g = np.load(os.path.join(golden_dir, f"denoise_{name}.npz"))
     H, W, wseed, iseed, nfr, batch = [int(v) for v in g["meta"]]
-    assert nfr == 2 and batch == 1
+    assert nfr == 2 and batch == (1 if name.startswith("b_") else 0)
     blob = synth.make_blob(wseed)
     xs = [synth.make_gbuffer(H, W, iseed, j) for j in range(nfr)]
-    outs, names = _run(ctx, blob, xs, H, W, bn_batch=True, carry=True)
+    outs, names = _run(ctx, blob, xs, H, W, bn_batch=bool(batch), carry=True)
+    tol = TOL                                              # plain 1e-3 absolute in both modes (measured 1.9e-4 / 8.4e-5 on frame 1)
     assert names[0] == R_PLANAR and names[1] == R and names[2] == R, names[:3]
     y = np.stack(outs)
     assert np.isfinite(y).all()
@@ -123,11 +127,11 @@ def test_register_staged_kernel_with_a_carried_hidden_state_against_the_referenc
         assert sel.sum() > 60000
         err = float(np.abs(flat[idx[sel]] - g["out_samples"][sel]).max())
         y64 = y[j].astype(np.float64).reshape(3, -1)
-        np.testing.assert_allclose(y64.mean(axis=1), g["out_mean"][j], atol=2e-5)
+        np.testing.assert_allclose(y64.mean(axis=1), g["out_mean"][j], atol=2e-5 * tol / TOL)
         np.testing.assert_allclose((y64 * y64).mean(axis=1), g["out_msq"][j], rtol=2e-4, atol=2e-5)
-        assert np.all(np.abs(np.abs(y64).max(axis=1) - g["out_absmax"][j]) <= TOL)
-        print(f"b_carry_384x640 frame {j}: max abs err vs the reference model {err:.2e}")
-        assert err <= TOL, (j, err)
+        assert np.all(np.abs(np.abs(y64).max(axis=1) - g["out_absmax"][j]) <= tol)
+        print(f"{name} frame {j}: max abs err vs the reference model {err:.2e} (bar {tol:.1e})")
+        assert err <= tol, (j, err)
     # the carried state itself: the six hidden tensors after frame 1 against the reference's summaries
     import torch
     for lvl, shp in enumerate(arch.hidden_shapes(H, W)):

@@ -127,7 +127,7 @@ def test_register_staged_kernel_with_a_carried_hidden_state_against_the_referenc
         assert sel.sum() > 60000
         err = float(np.abs(flat[idx[sel]] - g["out_samples"][sel]).max())
         y64 = y[j].astype(np.float64).reshape(3, -1)
-        np.testing.assert_allclose(y64.mean(axis=1), g["out_mean"][j], atol=2e-5 * tol / TOL)
+        np.testing.assert_allclose(y64.mean(axis=1), g["out_mean"][j], atol=2e-5, rtol=1e-5)   # (running statistics: channel means up to 18)
         np.testing.assert_allclose((y64 * y64).mean(axis=1), g["out_msq"][j], rtol=2e-4, atol=2e-5)
         assert np.all(np.abs(np.abs(y64).max(axis=1) - g["out_absmax"][j]) <= tol)
         print(f"{name} frame {j}: max abs err vs the reference model {err:.2e} (bar {tol:.1e})")

@@ -55,8 +55,9 @@ CASES = [
     ("b_reset_736x1280", 736, 1280, 568, 3, "batch", 1),      # stored as samples + moments (SAMPLED below)
     ("b_carry_384x640", 384, 640, 569, 4, "batch",  2),       # [r6] hidden CARRIED into frame 1 at a size conv3x3_f16x3r runs
     ("r_carry_384x640", 384, 640, 570, 5, "running", 2),      # [r6] the same with running-statistics BatchNorm (model.eval())
+    ("b_carry_736x1280", 736, 1280, 571, 6, "batch", 2),      # [r6] ... and at the benchmark size (levels 0 and 1 on conv3x3_f16x3r)
 ]
-SAMPLED = {"b_reset_736x1280": 65536, "b_carry_384x640": 131072, "r_carry_384x640": 131072}
+SAMPLED = {"b_reset_736x1280": 65536, "b_carry_384x640": 131072, "r_carry_384x640": 131072, "b_carry_736x1280": 131072}
 
 
 def hidden_summary(h):
